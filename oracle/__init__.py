@@ -1,0 +1,194 @@
+"""ctypes front-end of the CPU oracle (oracle/mc_oracle.c, oracle/density_ref.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package.  "parity unpinned" against an execution of the
+reference (see mc_oracle.h); pinned by table digests and analytic known answers.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libvtmc_oracle.so")
+_lib = None
+
+TRI_DTYPE = np.dtype([("p0", "<f4", 3), ("p1", "<f4", 3), ("p2", "<f4", 3),
+                      ("n0", "<f4", 3), ("n1", "<f4", 3), ("n2", "<f4", 3),
+                      ("block", "<i4")])
+assert TRI_DTYPE.itemsize == 76  # VoxelTerrain.cs:36
+
+
+class DensityParams(ctypes.Structure):
+    _fields_ = [("seed", ctypes.c_uint64), ("frequency", ctypes.c_float), ("octaves", ctypes.c_int32),
+                ("lacunarity", ctypes.c_float), ("gain", ctypes.c_float),
+                ("ramp_scale", ctypes.c_float), ("ramp_center", ctypes.c_float)]
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("mc_oracle.c", "density_ref.c", "mc_oracle.h", "Makefile")]
+    srcs.append(os.path.join(_HERE, "..", "volumetricterrain_amd", "csrc", "mc_tables_packed.h"))
+    stale = force or not os.path.exists(_SO) or any(
+        os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs if os.path.exists(s))
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+        L.vto_tables.argtypes = [vp, vp, vp]
+        L.vto_gather_tiles.argtypes = [vp, i64, i64, i64, vp, i32, vp]
+        L.vto_sample_normal.argtypes = [vp, i32, vp]
+        L.vto_collect_tri_num.argtypes = [vp, i32, vp]
+        L.vto_collect_tri_num.restype = ctypes.c_uint32
+        L.vto_marching_cube.argtypes = [vp, vp, vp, i32, vp, vp]
+        L.vto_marching_cube.restype = i64
+        L.vto_bin_triangles.argtypes = [vp, i64, i32, f32, vp, vp, vp]
+        L.vto_extract_grid.argtypes = [vp, i64, i64, i64, vp, i32, vp, i64, vp, vp, i32]
+        L.vto_extract_grid.restype = i64
+        L.vto_max_threads.restype = i32
+        L.vto_density_permutation.argtypes = [ctypes.c_uint64, vp]
+        L.vto_density_fill.argtypes = [ctypes.POINTER(DensityParams), i32, i32, i32, i32, i32, i32,
+                                       i64, i64, i64, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def tables():
+    edge = np.zeros(256, np.int32)
+    tri_num = np.zeros(256, np.int32)
+    vert = np.zeros(256 * 15, np.int32)
+    lib().vto_tables(_p(edge), _p(tri_num), _p(vert))
+    return edge, tri_num, vert.reshape(256, 15)
+
+
+def all_blocks(nx, ny, nz):
+    """Canonical dense block list: b = bx + nbx*(by + nby*bz)."""
+    nbx, nby, nbz = nx // 8, ny // 8, nz // 8
+    bz, by, bx = np.meshgrid(np.arange(nbz), np.arange(nby), np.arange(nbx), indexing="ij")
+    return np.stack([bx.ravel(), by.ravel(), bz.ravel()], axis=1).astype(np.int32)
+
+
+def elem_strides(grid):
+    """Element strides (sx, sy, sz) of a float32 array indexed grid[x, y, z] (any memory order)."""
+    assert grid.dtype == np.float32 and grid.ndim == 3
+    return tuple(int(s) // 4 for s in grid.strides)
+
+
+def gather_tiles(grid, block_list):
+    block_list = np.ascontiguousarray(block_list, np.int32)
+    out = np.empty((len(block_list), 1000), np.float32)
+    sx, sy, sz = elem_strides(grid)
+    lib().vto_gather_tiles(_p(grid), sx, sy, sz, _p(block_list), len(block_list), _p(out))
+    return out
+
+
+def sample_normal(samples):
+    B = samples.shape[0]
+    out = np.empty((B, 729, 3), np.float32)
+    lib().vto_sample_normal(_p(samples), B, _p(out))
+    return out
+
+
+def collect_tri_num(samples):
+    B = samples.shape[0]
+    flags = np.empty((B, 512), np.uint32)
+    n = lib().vto_collect_tri_num(_p(samples), B, _p(flags))
+    return int(n), flags
+
+
+def marching_cube(samples, normals, flags):
+    B = samples.shape[0]
+    total, _ = 0, None
+    offs = np.empty(B + 1, np.int32)
+    total = lib().vto_marching_cube(_p(samples), _p(normals), _p(flags), B, None, _p(offs))
+    tris = np.zeros(total, TRI_DTYPE)
+    lib().vto_marching_cube(_p(samples), _p(normals), _p(flags), B, _p(tris), _p(offs))
+    return tris, offs
+
+
+def extract_tiles(samples):
+    """The three reference dispatches on a B x 1000 tile buffer (VoxelTerrain.cs:365-427)."""
+    samples = np.ascontiguousarray(samples, np.float32).reshape(-1, 1000)
+    normals = sample_normal(samples)
+    n, flags = collect_tri_num(samples)
+    tris, offs = marching_cube(samples, normals, flags)
+    assert n == len(tris)
+    return tris, offs, flags.astype(np.uint8)
+
+
+def bin_triangles(tris, n_blocks, voxel_scale=1.0):
+    verts = np.empty((len(tris), 3, 3), np.float32)
+    nrms = np.empty((len(tris), 3, 3), np.float32)
+    offs = np.empty(n_blocks + 1, np.int32)
+    lib().vto_bin_triangles(_p(tris), len(tris), n_blocks, voxel_scale, _p(verts), _p(nrms), _p(offs))
+    return verts, nrms, offs
+
+
+def extract_grid(grid, block_list=None, threads=1, want_cases=False, count_only=False):
+    """grid is indexed [x, y, z] with shape (nx+2, ny+2, nz+2); any strides."""
+    nx, ny, nz = (d - 2 for d in grid.shape)
+    if block_list is None:
+        block_list = all_blocks(nx, ny, nz)
+    block_list = np.ascontiguousarray(block_list, np.int32)
+    B = len(block_list)
+    sx, sy, sz = elem_strides(grid)
+    offs = np.empty(B + 1, np.int32)
+    cases = np.empty((B, 512), np.uint8) if want_cases else None
+    total = lib().vto_extract_grid(_p(grid), sx, sy, sz, _p(block_list), B, None, 0, _p(offs),
+                                   _p(cases), threads)
+    if count_only:
+        return int(total), offs, cases
+    tris = np.zeros(total, TRI_DTYPE)
+    got = lib().vto_extract_grid(_p(grid), sx, sy, sz, _p(block_list), B, _p(tris), total, _p(offs),
+                                 None, threads)
+    assert got == total
+    return tris, offs, cases
+
+
+def max_threads():
+    return int(lib().vto_max_threads())
+
+
+def density_params(kind, n, seed=1337):
+    """perlin3d f = 8/N; fbm8 = 8 octaves, lacunarity 2, gain .5, f = 4/N, minus ramp."""
+    if kind == "perlin3d":
+        return DensityParams(seed, 8.0 / n, 1, 2.0, 0.5, 0.0, 0.0)
+    if kind == "fbm8":
+        return DensityParams(seed, 4.0 / n, 8, 2.0, 0.5, 2.0 / n, n / 2.0)
+    raise ValueError(kind)
+
+
+def density_volume(kind, n, origin=(0, 0, 0), dims=None, seed=1337, order="x"):
+    """Returns an array indexed [x, y, z].  order='x': x fastest in memory (the build's native
+    layout); order='z': z fastest (a C# float[,,], VoxelTerrain.cs:145)."""
+    if dims is None:
+        dims = (n + 2, n + 2, n + 2)
+    prm = density_params(kind, n, seed)
+    dx, dy, dz = dims
+    if order == "x":
+        mem = np.empty((dz, dy, dx), np.float32)
+        grid = mem.transpose(2, 1, 0)
+    else:
+        grid = np.empty((dx, dy, dz), np.float32)
+    sx, sy, sz = elem_strides(grid)
+    lib().vto_density_fill(ctypes.byref(prm), origin[0], origin[1], origin[2], dx, dy, dz,
+                           sx, sy, sz, _p(grid))
+    return grid
+
+
+def permutation(seed=1337):
+    perm = np.zeros(256, np.uint8)
+    lib().vto_density_permutation(seed, _p(perm))
+    return perm
