@@ -1,0 +1,173 @@
+/*
+ * vtmc.h -- C ABI of the MI355X-native marching-cubes extractor (libvtmc.so).
+ *
+ * Drop-in boundary for the GPU section of PGRTerrain.Render.VoxelTerrain.BatchUpdate
+ * (reference: Unity-Project/Assets/Scripts/VoxelTerrain.cs:330-477), which today drives three
+ * Unity compute shaders (Shaders/SampleNormal.compute, CollectTriNum.compute, MarchingCube.compute)
+ * through nine ComputeBuffer bindings (VoxelTerrain.cs:370-421).  Every entry point is cdecl,
+ * `extern "C"`, takes only plain pointers / integers / the 76-byte POD below, and never throws:
+ * the return value is a status (0 = OK, negative = error, text via vtmc_last_error).
+ *
+ * Ownership: host memory passed in is borrowed for the duration of the call only; all device
+ * memory is owned by the context.  Calls on one context are serialised by the caller
+ * (the reference calls from the Unity main thread only, TerrainEngine.cs:145-149); different
+ * contexts may be used from different threads.  Host entry points block until results are complete.
+ *
+ * Canonical triangle order (the reference's order is whatever its atomic append produces,
+ * MarchingCube.compute:160-162): (block index in the submitted list, cell x + 8y + 64z, table
+ * triangle i).  The host can therefore slice per block with block_tri_offsets instead of binning
+ * (VoxelTerrain.cs:437-446).
+ */
+#ifndef VTMC_H
+#define VTMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VTMC_BLOCK_SIZE 8          /* VoxelTerrain.cs:54  blockSize */
+#define VTMC_TILE_SAMPLES 1000     /* (blockSize+2)^3, VoxelTerrain.cs:337-341 */
+#define VTMC_MAX_TRIS_PER_CELL 5   /* VoxelTerrain.cs:480 maxTriNumPerCell */
+
+/* status codes */
+#define VTMC_OK 0
+#define VTMC_ERR_INVALID_ARG (-1)  /* null pointer, negative count ... */
+#define VTMC_ERR_DIMS (-2)         /* dims not a multiple of 8 (VoxelTerrain.cs:138-139) or block out of range */
+#define VTMC_ERR_CAPACITY (-3)     /* destination smaller than the triangle count */
+#define VTMC_ERR_DEVICE (-4)       /* HIP runtime error (text in vtmc_last_error) */
+#define VTMC_ERR_NO_RESULT (-5)    /* read_* before any extract_* */
+#define VTMC_ERR_TOO_LARGE (-6)    /* more than 2^31-1 triangles or blocks */
+
+/* Wire format of one triangle -- replaces the private CSTriangle read-back struct
+ * (VoxelTerrain.cs:23-37; HLSL twin MarchingCube.compute:18-27).  76 bytes, packed.  Positions
+ * are block-local in cell units [0,8]; `block` is the index into the submitted block list. */
+typedef struct vtmc_triangle {
+    float position0[3];
+    float position1[3];
+    float position2[3];
+    float normal0[3];
+    float normal1[3];
+    float normal2[3];
+    int32_t block;
+} vtmc_triangle;
+
+typedef struct vtmc_ctx vtmc_ctx;
+
+/* Replaces the table uploads of VoxelTerrain.Init (VoxelTerrain.cs:151-156): binds HIP device
+ * `device`, uploads the lookup tables, creates the stream and reusable scratch. */
+int32_t vtmc_create(int32_t device, vtmc_ctx **out_ctx);
+
+/* Replaces the ComputeBuffer.Release calls of VoxelTerrain.Free (VoxelTerrain.cs:228-244) and of
+ * BatchUpdate's epilogue (VoxelTerrain.cs:469-476). */
+int32_t vtmc_destroy(vtmc_ctx *ctx);
+
+/* UTF-8 text of the last error on this context ("" if none).  ctx may be NULL (global create error). */
+const char *vtmc_last_error(const vtmc_ctx *ctx);
+
+/* Replaces bufferSamples.SetData + the three Dispatch calls + bufferTriNum.GetData
+ * (VoxelTerrain.cs:365-395).  `samples` = n_blocks tiles of 10x10x10 floats, x fastest, exactly the
+ * array BatchUpdate builds (VoxelTerrain.cs:341-361).  *tri_count receives T (0 is success, the
+ * reference's early-out VoxelTerrain.cs:396-405). */
+int32_t vtmc_extract_blocks(vtmc_ctx *ctx, const float *samples, int32_t n_blocks, int32_t *tri_count);
+
+/* New: removes the tile gather (VoxelTerrain.cs:337-361).  Reads the (nx+2, ny+2, nz+2)-sample
+ * grid in place: sample (x,y,z) = grid[x*stride_x + y*stride_y + z*stride_z] (element strides), so
+ * a pinned C# float[W+2,E+2,H+2] (z fastest, VoxelTerrain.cs:145) is passed with strides
+ * ((E+2)*(H+2), H+2, 1).  block_list = n_blocks (bx,by,bz) triples (the dirty list
+ * VoxelTerrain.cs:321); NULL = every block, ordered bx + nbx*(by + nby*bz), n_blocks ignored. */
+int32_t vtmc_extract_grid(vtmc_ctx *ctx, const float *grid, int32_t nx, int32_t ny, int32_t nz,
+                          int64_t stride_x, int64_t stride_y, int64_t stride_z,
+                          const int32_t *block_list, int32_t n_blocks, int32_t *tri_count);
+
+/* Multi-GPU host entry: the grid is cut into chunks of chunk_cells^3 cells, chunk c
+ * (c = cx + ncx*(cy + ncy*cz)) belongs to rank c % world_size.  Extracts this rank's chunks only,
+ * chunk-major, blocks in canonical order inside each chunk.  chunk_counts receives for each LOCAL
+ * chunk {vertex count, triangle count}; *n_local_chunks how many.  No collective is issued here:
+ * the caller all-gathers chunk_counts (RCCL) -- see volumetricterrain_amd/sharding.py. */
+int32_t vtmc_extract_grid_sharded(vtmc_ctx *ctx, const float *grid, int32_t nx, int32_t ny, int32_t nz,
+                                  int64_t stride_x, int64_t stride_y, int64_t stride_z,
+                                  int32_t chunk_cells, int32_t rank, int32_t world_size,
+                                  uint32_t *chunk_counts, int32_t chunk_counts_capacity,
+                                  int32_t *n_local_chunks, int32_t *tri_count);
+
+/* Replaces bufferMeshes.GetData(csTriangles) (VoxelTerrain.cs:426-427).  Copies the T triangles of
+ * the last extract_* in canonical order.  block_tri_offsets (optional, n_blocks+1 entries) receives
+ * the exclusive prefix of per-block triangle counts. */
+int32_t vtmc_read_triangles(vtmc_ctx *ctx, vtmc_triangle *dst, int64_t capacity, int32_t *block_tri_offsets);
+
+/* The _CornerFlags buffer of the last extract_* (CollectTriNum.compute:56-62) as one byte per
+ * cell: dst[512*b + x + 8y + 64z].  Parity / debugging aid; capacity in bytes. */
+int32_t vtmc_read_cases(vtmc_ctx *ctx, uint8_t *dst, int64_t capacity);
+
+/* Number of blocks / triangles of the last extract_*. */
+int32_t vtmc_last_counts(const vtmc_ctx *ctx, int32_t *n_blocks, int32_t *tri_count);
+
+/* ------------------------------------------------------------------------------------------
+ * Device-resident entry points: same extraction, inputs already in HBM (what a GPU-resident host,
+ * the sharded driver and bench.py use).  Pointers prefixed d_ are device pointers on ctx's device.
+ * ------------------------------------------------------------------------------------------ */
+
+/* A batch of equally shaped volumes: volume v starts at d_samples + v*volume_stride and holds
+ * (nx+2, ny+2, nz+2) samples addressed with the element strides.  One 1026^3 grid is a batch of 1;
+ * the reference's tile buffer is a batch of n_blocks volumes with nx=ny=nz=8, strides (1,10,100),
+ * volume_stride 1000; "1024^3 as 8^3 chunks of 128^3" is a batch of 512 with nx=ny=nz=128. */
+typedef struct vtmc_volume_batch {
+    const float *d_samples;
+    int32_t nx, ny, nz;
+    int64_t stride_x, stride_y, stride_z;
+    int32_t n_volumes;
+    int64_t volume_stride;
+} vtmc_volume_batch;
+
+#define VTMC_FLAG_WANT_CASES 1u    /* also materialise the per-cell case bytes (slower generic classify) */
+#define VTMC_FLAG_NO_DENSE_PATH 2u /* force the per-block classify kernel (A/B testing) */
+
+/* Extract every block of every volume (block id = v*blocks_per_volume + bx + nbx*(by + nby*bz)).
+ * `stream` is a hipStream_t (NULL = the context's own stream).  Blocks until T is known. */
+int32_t vtmc_extract_volumes_device(vtmc_ctx *ctx, const vtmc_volume_batch *batch, void *stream,
+                                    uint32_t flags, int64_t *tri_count);
+
+/* Device pointers to the results of the last extract_* (valid until the next extract_* / destroy):
+ * triangles (T x 76 B), block_tri_offsets (n_blocks+1 x u32), volume_counts (n_volumes x
+ * {vertices, triangles} u32 -- the array SURVEY.md 8e all-gathers).  Any out pointer may be NULL. */
+int32_t vtmc_device_results(vtmc_ctx *ctx, const vtmc_triangle **d_triangles,
+                            const uint32_t **d_block_tri_offsets, const uint32_t **d_volume_counts);
+
+/* Pre-size the triangle buffer (otherwise it grows on demand and the emit stage is re-run once). */
+int32_t vtmc_reserve_triangles(vtmc_ctx *ctx, int64_t capacity);
+
+/* Per-stage device time of the last extract_* in milliseconds, measured with HIP events on the
+ * stream the kernels ran on: ms[0] classify+count, ms[1] scan, ms[2] emit, ms[3] whole call.
+ * The reference's only timing hook is the commented-out timer at VoxelTerrain.cs:363/467. */
+int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4]);
+
+/* Synthetic density sampler (the reference has no noise field of its own):
+ * density = sum_{o<octaves} gain^o * perlin(p*frequency*lacunarity^o) - (p.y - ramp_center)*ramp_scale,
+ * p = volume origin + sample index, FP32, Perlin 2002 improved noise with a SplitMix64 permutation. */
+typedef struct vtmc_density_params {
+    uint64_t seed;
+    float frequency;
+    int32_t octaves;
+    float lacunarity;
+    float gain;
+    float ramp_scale;
+    float ramp_center;
+} vtmc_density_params;
+
+/* Fill n_volumes volumes of (dim_x, dim_y, dim_z) samples; volume v has global sample origin
+ * origins[3v..3v+2] (host array) and is written at d_out + v*volume_stride with element strides. */
+int32_t vtmc_density_fill_device(vtmc_ctx *ctx, const vtmc_density_params *params,
+                                 const int32_t *origins, int32_t n_volumes,
+                                 int32_t dim_x, int32_t dim_y, int32_t dim_z,
+                                 int64_t stride_x, int64_t stride_y, int64_t stride_z,
+                                 int64_t volume_stride, float *d_out, void *stream);
+
+/* Library / build identification: "vtmc <version> gfx950". */
+const char *vtmc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTMC_H */

@@ -1,0 +1,224 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): cube cases, per-block counts/offsets and the triangle -> (block,
+cell, table-triangle) structure bit-exact; interpolated positions and normals within 1e-5 absolute.
+"""
+import numpy as np
+import pytest
+
+import fields
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5  # north_star tolerance for positions / normals
+
+
+@pytest.fixture(scope="module")
+def ex():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import volumetricterrain_amd as vt
+    assert vt.library_path() is not None
+    e = vt.Extractor(0)
+    yield e
+    e.close()
+
+
+def assert_tris_match(got, want, atol=ATOL):
+    assert len(got) == len(want)
+    assert np.array_equal(got["block"], want["block"])
+    worst = 0.0
+    for f in ("p0", "p1", "p2", "n0", "n1", "n2"):
+        g, w = got[f], want[f]
+        nan_g, nan_w = np.isnan(g), np.isnan(w)
+        assert np.array_equal(nan_g, nan_w), "NaN pattern differs in " + f
+        d = np.abs(np.where(nan_w, 0, g) - np.where(nan_w, 0, w))
+        worst = max(worst, float(d.max()) if d.size else 0.0)
+    assert worst <= atol, "max abs deviation %g > %g" % (worst, atol)
+    return worst
+
+
+def test_tile_batch_matches_oracle(ex, oracle_mod):
+    """vtmc_extract_blocks on the reference's own tile layout (VoxelTerrain.cs:341-361)."""
+    g = oracle_mod.density_volume("perlin3d", 32)
+    tiles = oracle_mod.gather_tiles(g, oracle_mod.all_blocks(32, 32, 32))
+    tiles = np.concatenate([tiles, fields.all_cases_tile()])
+    want, want_offs, want_cases = oracle_mod.extract_tiles(tiles)
+    T = ex.extract_blocks(tiles)
+    assert T == len(want)
+    got, offs = ex.read_triangles()
+    assert np.array_equal(offs, want_offs)
+    assert np.array_equal(ex.read_cases(), want_cases)
+    assert_tris_match(got, want)
+
+
+@pytest.mark.parametrize("order", ["x", "z"])
+def test_grid_in_place_matches_oracle(ex, oracle_mod, order):
+    """vtmc_extract_grid, x-fastest (dense streaming classify) and C# z-fastest layouts."""
+    g = oracle_mod.density_volume("perlin3d", 64, order=order)
+    want, want_offs, want_cases = oracle_mod.extract_grid(g, want_cases=True, threads=8)
+    T = ex.extract_grid(g)
+    assert T == len(want)
+    got, offs = ex.read_triangles()
+    assert np.array_equal(offs, want_offs)
+    assert np.array_equal(ex.read_cases(), want_cases)
+    assert_tris_match(got, want)
+
+
+def test_non_cubic_and_partial_segments(ex, oracle_mod):
+    """nx = 40 / 72 exercise partial 64-lane segments of the dense classify kernel."""
+    for n in ((40, 16, 24), (72, 8, 16), (136, 8, 8)):
+        g = fields.random_field(n, seed=n[0])
+        want, want_offs, _ = oracle_mod.extract_grid(g, threads=8)
+        assert ex.extract_grid(g) == len(want)
+        got, offs = ex.read_triangles()
+        assert np.array_equal(offs, want_offs)
+        assert_tris_match(got, want)
+
+
+def test_dirty_block_list(ex, oracle_mod):
+    """Arbitrary, unordered dirty lists (VoxelTerrain.cs:321: hash-set order), both upload paths."""
+    g = oracle_mod.density_volume("perlin3d", 64)
+    blocks = oracle_mod.all_blocks(64, 64, 64)
+    rng = np.random.default_rng(5)
+    for count in (7, 300):   # 7: host tile gather path; 300: grid upload + device list
+        sel = blocks[rng.permutation(len(blocks))[:count]]
+        want, want_offs, _ = oracle_mod.extract_grid(g, sel)
+        assert ex.extract_grid(g, sel) == len(want)
+        got, offs = ex.read_triangles()
+        assert np.array_equal(offs, want_offs)
+        assert_tris_match(got, want)
+
+
+def test_plane_sphere_empty(ex, oracle_mod):
+    g = fields.plane((32, 16, 32), 5.375)
+    assert ex.extract_grid(g) == 2 * 32 * 32
+    tris = ex.read_triangles(False)
+    for f in ("n0", "n1", "n2"):
+        assert (tris[f] == np.array([0, 1, 0], np.float32)).all()
+    for f in ("p0", "p1", "p2"):
+        assert (tris[f][:, 1] == np.float32(5.375)).all()
+    s = fields.sphere((32, 32, 32), (16.3, 15.6, 16.9), 10.2)
+    want, _, _ = oracle_mod.extract_grid(s)
+    assert ex.extract_grid(s) == len(want)
+    assert_tris_match(ex.read_triangles(False), want)
+    for value in (-1.0, 0.0, 2.0, np.nan):
+        assert ex.extract_grid(fields.constant((32, 8, 8), value)) == 0
+        t, offs = ex.read_triangles()
+        assert len(t) == 0 and (offs == 0).all()
+        assert (ex.read_cases() == (0xFF if value > 0 else 0)).all()
+    assert ex.extract_blocks(np.zeros((0, 1000), np.float32)) == 0
+
+
+def test_error_behaviour(ex):
+    import volumetricterrain_amd as vt
+    with pytest.raises(vt.VtmcError) as e:
+        ex.extract_grid(np.zeros((12, 10, 10), np.float32))   # 10 cells: not a multiple of 8
+    assert e.value.code == -2 and "block size must align" in str(e.value)   # VoxelTerrain.cs:138-139
+    with pytest.raises(vt.VtmcError) as e:
+        ex.extract_grid(np.zeros((10, 10, 10), np.float32), np.array([[1, 0, 0]], np.int32))
+    assert e.value.code == -2
+
+
+def test_device_volume_batch_matches_grid(ex, oracle_mod):
+    """Config 'grid as chunks': 8 chunks of 32^3 with halos in one launch set == per-chunk oracle;
+    dense and per-block classify kernels agree."""
+    import torch
+    n, c = 64, 32
+    g = oracle_mod.density_volume("perlin3d", n)
+    chunks, want = [], []
+    for cz in range(2):
+        for cy in range(2):
+            for cx in range(2):
+                sub = np.ascontiguousarray(
+                    g[cx * c:cx * c + c + 2, cy * c:cy * c + c + 2, cz * c:cz * c + c + 2].transpose(2, 1, 0))
+                chunks.append(sub)    # memory order z, y, x  => x fastest
+                t, _, _ = oracle_mod.extract_grid(sub.transpose(2, 1, 0))
+                t = t.copy()
+                t["block"] += len(want) * (c // 8) ** 3
+                want.append(t)
+    want_all = np.concatenate(want)
+    d = torch.from_numpy(np.stack(chunks)).cuda()
+    dim = c + 2
+    for flags in (0, 2):
+        T = ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 8, dim ** 3, flags=flags)
+        assert T == len(want_all)
+        got, offs = ex.read_triangles()
+        assert_tris_match(got, want_all)
+    # volume_counts = {vertices, triangles} per chunk, the array that gets all-gathered
+    _, _, vc_ptr = ex.device_results()
+    from volumetricterrain_amd import sharding
+    vc = sharding.copy_device_u32(vc_ptr, 16).reshape(8, 2)
+    assert np.array_equal(vc[:, 1], [len(w) for w in want])
+    assert np.array_equal(vc[:, 0], 3 * vc[:, 1])
+
+
+def test_sharded_host_entry(ex, oracle_mod):
+    g = oracle_mod.density_volume("perlin3d", 64)
+    whole, _, _ = oracle_mod.extract_grid(g, threads=8)
+    total = 0
+    per_rank = []
+    for rank in range(2):
+        T, counts = ex.extract_grid_sharded(g, 32, rank, 2)
+        assert counts[:, 1].sum() == T and np.array_equal(counts[:, 0], 3 * counts[:, 1])
+        per_rank.append(counts)
+        total += T
+    assert total == len(whole)
+    assert len(per_rank[0]) == 4 and len(per_rank[1]) == 4
+
+
+def test_density_sampler_matches_cpu_twin(ex, oracle_mod):
+    import torch
+    import volumetricterrain_amd as vt
+    for kind in ("perlin3d", "fbm8"):
+        n = 64
+        want = oracle_mod.density_volume(kind, n)           # [x,y,z], x fastest
+        d = torch.empty((n + 2) ** 3, dtype=torch.float32, device="cuda")
+        dim = n + 2
+        ex.density_fill_device(vt.density_params(kind, n), [[0, 0, 0]], (dim, dim, dim), (1, dim, dim * dim), 0,
+                               d.data_ptr())
+        got = d.cpu().numpy().reshape(dim, dim, dim).transpose(2, 1, 0)
+        assert np.abs(got - want).max() <= 2e-6
+
+
+def test_config_256_full_compare(ex, oracle_mod):
+    """BASELINE config[1]: 256^3 perlin3d, whole output against the oracle."""
+    g = oracle_mod.density_volume("perlin3d", 256)
+    want, want_offs, _ = oracle_mod.extract_grid(g, threads=oracle_mod.max_threads())
+    assert ex.extract_grid(g) == len(want) == 2655156
+    got, offs = ex.read_triangles()
+    assert np.array_equal(offs, want_offs)
+    assert_tris_match(got, want)
+
+
+def test_config_1024_chunked_properties(ex, oracle_mod):
+    """BASELINE config[2]: 1024^3 as 512 chunks of 128^3 generated on the device.  Size-independent
+    checks: per-chunk counts equal the oracle's count pass on a sample of chunks, offsets are a
+    valid exclusive scan, every record is well formed, one sampled chunk matches the oracle fully."""
+    import torch
+    import volumetricterrain_amd as vt
+    from volumetricterrain_amd import sharding
+    n, c = 1024, 128
+    dim = c + 2
+    origins = sharding.chunk_origins(n, c)
+    d = torch.empty(len(origins) * dim ** 3, dtype=torch.float32, device="cuda")
+    ex.density_fill_device(vt.density_params("perlin3d", n), origins, (dim, dim, dim), (1, dim, dim * dim),
+                           dim ** 3, d.data_ptr())
+    T = ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), len(origins), dim ** 3)
+    tri_ptr, off_ptr, vc_ptr = ex.device_results()
+    bpv = (c // 8) ** 3
+    offs = sharding.copy_device_u32(off_ptr, len(origins) * bpv + 1)
+    vc = sharding.copy_device_u32(vc_ptr, 2 * len(origins)).reshape(-1, 2)
+    assert offs[0] == 0 and offs[-1] == T and (np.diff(offs.astype(np.int64)) >= 0).all()
+    assert vc[:, 1].sum() == T
+    assert np.array_equal(np.diff(offs.astype(np.int64))[: bpv * len(origins)].reshape(len(origins), bpv).sum(1), vc[:, 1])
+    # sampled chunks against the oracle, fed the SAME device-generated array
+    for v in (0, 77, 300, 511):
+        sub = d[v * dim ** 3:(v + 1) * dim ** 3].cpu().numpy().reshape(dim, dim, dim).transpose(2, 1, 0)
+        want, want_offs, _ = oracle_mod.extract_grid(sub, threads=oracle_mod.max_threads())
+        assert vc[v, 1] == len(want)
+        got = sharding.copy_device_bytes(tri_ptr + 76 * int(offs[v * bpv]), 76 * len(want)).view(vt.TRI_DTYPE)
+        want = want.copy()
+        want["block"] += v * bpv
+        assert_tris_match(got, want)
+        assert np.array_equal(offs[v * bpv:(v + 1) * bpv + 1].astype(np.int64) - int(offs[v * bpv]), want_offs)

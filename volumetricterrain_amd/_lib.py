@@ -1,0 +1,90 @@
+"""ctypes binding of libvtmc.so -- the same C ABI a C# host binds with [DllImport].
+
+There is no CPU fallback: if the library is missing it is built with hipcc; if that fails, or the
+library cannot be loaded, importing raises.  Creating a context without a HIP device fails with
+VtmcError (vtmc_create returns VTMC_ERR_DEVICE).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+TRI_DTYPE = np.dtype([("p0", "<f4", 3), ("p1", "<f4", 3), ("p2", "<f4", 3),
+                      ("n0", "<f4", 3), ("n1", "<f4", 3), ("n2", "<f4", 3),
+                      ("block", "<i4")])
+assert TRI_DTYPE.itemsize == 76  # CSTriangle.stride, VoxelTerrain.cs:36
+
+OK = 0
+ERR_INVALID_ARG, ERR_DIMS, ERR_CAPACITY, ERR_DEVICE, ERR_NO_RESULT, ERR_TOO_LARGE = -1, -2, -3, -4, -5, -6
+FLAG_WANT_CASES, FLAG_NO_DENSE_PATH = 1, 2
+
+# every symbol include/vtmc.h declares (tests/test_abi_symbols.py checks the header against this)
+SYMBOLS = [
+    "vtmc_version", "vtmc_create", "vtmc_destroy", "vtmc_last_error", "vtmc_extract_blocks",
+    "vtmc_extract_grid", "vtmc_extract_grid_sharded", "vtmc_read_triangles", "vtmc_read_cases",
+    "vtmc_last_counts", "vtmc_extract_volumes_device", "vtmc_device_results",
+    "vtmc_reserve_triangles", "vtmc_last_stage_ms", "vtmc_density_fill_device",
+]
+
+
+class VolumeBatch(ctypes.Structure):
+    _fields_ = [("d_samples", ctypes.c_void_p), ("nx", ctypes.c_int32), ("ny", ctypes.c_int32),
+                ("nz", ctypes.c_int32), ("stride_x", ctypes.c_int64), ("stride_y", ctypes.c_int64),
+                ("stride_z", ctypes.c_int64), ("n_volumes", ctypes.c_int32),
+                ("volume_stride", ctypes.c_int64)]
+
+
+class DensityParams(ctypes.Structure):
+    _fields_ = [("seed", ctypes.c_uint64), ("frequency", ctypes.c_float), ("octaves", ctypes.c_int32),
+                ("lacunarity", ctypes.c_float), ("gain", ctypes.c_float),
+                ("ramp_scale", ctypes.c_float), ("ramp_center", ctypes.c_float)]
+
+
+class VtmcError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("vtmc error %d: %s" % (code, text))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load (building if stale) libvtmc.so and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build()
+    L = ctypes.CDLL(path)
+    vp, i32, i64, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32
+    P = ctypes.POINTER
+    L.vtmc_version.restype = ctypes.c_char_p
+    L.vtmc_create.argtypes = [i32, P(vp)]
+    L.vtmc_destroy.argtypes = [vp]
+    L.vtmc_last_error.argtypes = [vp]
+    L.vtmc_last_error.restype = ctypes.c_char_p
+    L.vtmc_extract_blocks.argtypes = [vp, vp, i32, P(i32)]
+    L.vtmc_extract_grid.argtypes = [vp, vp, i32, i32, i32, i64, i64, i64, vp, i32, P(i32)]
+    L.vtmc_extract_grid_sharded.argtypes = [vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, i32,
+                                            vp, i32, P(i32), P(i32)]
+    L.vtmc_read_triangles.argtypes = [vp, vp, i64, vp]
+    L.vtmc_read_cases.argtypes = [vp, vp, i64]
+    L.vtmc_last_counts.argtypes = [vp, P(i32), P(i32)]
+    L.vtmc_extract_volumes_device.argtypes = [vp, P(VolumeBatch), vp, u32, P(i64)]
+    L.vtmc_device_results.argtypes = [vp, P(vp), P(vp), P(vp)]
+    L.vtmc_reserve_triangles.argtypes = [vp, i64]
+    L.vtmc_last_stage_ms.argtypes = [vp, P(ctypes.c_float * 4)]
+    L.vtmc_density_fill_device.argtypes = [vp, P(DensityParams), vp, i32, i32, i32, i32,
+                                           i64, i64, i64, i64, vp, vp]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is ctypes.c_int:
+            fn.restype = i32
+    _lib = L
+    return L
+
+
+def library_path():
+    return _build.LIB if os.path.exists(_build.LIB) else None

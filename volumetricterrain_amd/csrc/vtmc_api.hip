@@ -1,0 +1,539 @@
+// vtmc_api.hip -- the C ABI of include/vtmc.h: context, scratch management and the host-side
+// control flow that VoxelTerrain.BatchUpdate performs around its three dispatches
+// (reference: Unity-Project/Assets/Scripts/VoxelTerrain.cs:330-477).
+//
+// Differences from the reference's control flow, by design:
+//  * buffers are owned by the context and only grow (the reference allocates and releases six
+//    ComputeBuffers per call, VoxelTerrain.cs:368-414, 469-476);
+//  * there is no mid-pipeline read-back (VoxelTerrain.cs:394-395): classify -> scan -> emit are
+//    queued back to back, {T, nActive} live in device memory, and the host reads T once at the end;
+//    the emit kernel itself refuses to run past the triangle buffer's capacity, in which case the
+//    buffer is grown and only the emit stage is queued again;
+//  * no CPU fallback of any kind: without a HIP device vtmc_create fails.
+#include "../../include/vtmc.h"
+#include "mc_tables_packed.h"
+#include "vtmc_internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace vtmc;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct vtmc_ctx {
+    int device = 0;
+    int n_cus = 256;
+    hipStream_t stream = nullptr;
+    DeviceTables tables{nullptr, nullptr};
+    DevBuf d_vert, d_trinum;
+    DevBuf counts, offsets, active, partials, totals, volcounts, cases, tris, input, list, perm, origins;
+    uint32_t *h_totals = nullptr;  // pinned, 2 x u32
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float stage_ms[4] = {0, 0, 0, 0};
+    // last result
+    bool has_result = false;
+    BlockSpace last_space{};
+    int last_blocks = 0;
+    int last_volumes = 0;
+    int64_t last_tris = 0;
+    uint64_t perm_seed = 0;
+    bool perm_valid = false;
+    std::string err;
+};
+
+namespace {
+
+int fail(vtmc_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define VTMC_HIP(ctx, expr)                                                                          \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(ctx, VTMC_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                         \
+    } while (0)
+
+int ensure(vtmc_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (b.bytes >= bytes && b.p) return VTMC_OK;
+    if (b.p) VTMC_HIP(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    size_t want = std::max<size_t>(bytes, 256);
+    VTMC_HIP(ctx, hipMalloc(&b.p, want));
+    b.bytes = want;
+    return VTMC_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+// classify -> scan -> emit on `stream`; fills last_* and stage_ms.
+int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t flags, hipStream_t stream,
+                 int64_t *tri_count)
+{
+    BlockSpace sp = sp_in;
+    const int B = sp.n_blocks;
+    ctx->has_result = false;
+    if (B == 0) {
+        ctx->has_result = true;
+        ctx->last_space = sp;
+        ctx->last_blocks = 0;
+        ctx->last_volumes = n_volumes;
+        ctx->last_tris = 0;
+        memset(ctx->stage_ms, 0, sizeof ctx->stage_ms);
+        if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t))) return rc;
+        VTMC_HIP(ctx, hipMemsetAsync(ctx->offsets.p, 0, sizeof(uint32_t), stream));
+        VTMC_HIP(ctx, hipStreamSynchronize(stream));
+        if (tri_count) *tri_count = 0;
+        return VTMC_OK;
+    }
+    const int n_tiles = (B + kScanTile - 1) / kScanTile;
+    if (int rc = ensure(ctx, ctx->counts, sizeof(uint32_t) * (size_t)B)) return rc;
+    if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
+    if (int rc = ensure(ctx, ctx->active, sizeof(int32_t) * (size_t)B)) return rc;
+    if (int rc = ensure(ctx, ctx->partials, sizeof(uint32_t) * 2 * (size_t)n_tiles)) return rc;
+    if (int rc = ensure(ctx, ctx->totals, sizeof(uint32_t) * 2)) return rc;
+    if (int rc = ensure(ctx, ctx->volcounts, sizeof(uint32_t) * 2 * (size_t)std::max(n_volumes, 1))) return rc;
+    uint8_t *d_cases = nullptr;
+    if (flags & VTMC_FLAG_WANT_CASES) {
+        if (int rc = ensure(ctx, ctx->cases, (size_t)B * 512)) return rc;
+        d_cases = (uint8_t *)ctx->cases.p;
+    }
+    if (!ctx->tris.p)
+        if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * ((size_t)1 << 20))) return rc;
+
+    const bool dense = !sp.list && sp.sx == 1 && sp.nx >= 32 && !(flags & (VTMC_FLAG_WANT_CASES | VTMC_FLAG_NO_DENSE_PATH));
+
+    VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
+    if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, stream));
+    else VTMC_HIP(ctx, launch_classify_blocks(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_cases, ctx->n_cus, stream));
+    VTMC_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
+    VTMC_HIP(ctx, launch_scan((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p,
+                              (int32_t *)ctx->active.p, (uint32_t *)ctx->partials.p, (uint32_t *)ctx->totals.p,
+                              sp.bpv, n_volumes, (uint32_t *)ctx->volcounts.p, stream));
+    VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
+
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const size_t cap = std::min<size_t>(ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
+        VTMC_HIP(ctx, launch_emit(sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const int32_t *)ctx->active.p,
+                                  (const uint32_t *)ctx->totals.p, (uint32_t)cap, ctx->tris.p, ctx->n_cus, stream));
+        VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
+        VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->totals.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        VTMC_HIP(ctx, hipStreamSynchronize(stream));
+        const uint32_t T = ctx->h_totals[0];
+        if (T > 0x7fffffffu) return fail(ctx, VTMC_ERR_TOO_LARGE, "%u triangles exceed the int32 range of the ABI", T);
+        if ((size_t)T <= cap) break;
+        if (attempt == 1) return fail(ctx, VTMC_ERR_DEVICE, "triangle buffer still too small after growing");
+        // grow (with head-room so a slowly changing field does not regrow every frame) and redo the emit stage
+        size_t want = (size_t)T + (size_t)T / 8 + 1024;
+        if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * want)) return rc;
+        VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
+    }
+    float a = 0, b = 0, c = 0;
+    VTMC_HIP(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+    VTMC_HIP(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+    VTMC_HIP(ctx, hipEventElapsedTime(&c, ctx->ev[2], ctx->ev[3]));
+    ctx->stage_ms[0] = a;
+    ctx->stage_ms[1] = b;
+    ctx->stage_ms[2] = c;
+    ctx->stage_ms[3] = a + b + c;
+
+    ctx->has_result = true;
+    ctx->last_space = sp;
+    ctx->last_blocks = B;
+    ctx->last_volumes = n_volumes;
+    ctx->last_tris = ctx->h_totals[0];
+    if (tri_count) *tri_count = ctx->last_tris;
+    return VTMC_OK;
+}
+
+int check_dims(vtmc_ctx *ctx, int nx, int ny, int nz)
+{
+    if (nx <= 0 || ny <= 0 || nz <= 0) return fail(ctx, VTMC_ERR_DIMS, "non-positive grid size %dx%dx%d", nx, ny, nz);
+    // VoxelTerrain.cs:138-139 "block size must align to terrain size"
+    if (nx % 8 || ny % 8 || nz % 8)
+        return fail(ctx, VTMC_ERR_DIMS, "block size must align to terrain size (%dx%dx%d is not a multiple of 8)", nx, ny, nz);
+    return VTMC_OK;
+}
+
+// upload the memory span a strided host grid occupies; returns device pointer in ctx->input
+int upload_grid(vtmc_ctx *ctx, const float *grid, int nx, int ny, int nz, int64_t sx, int64_t sy, int64_t sz)
+{
+    if (sx <= 0 || sy <= 0 || sz <= 0) return fail(ctx, VTMC_ERR_INVALID_ARG, "strides must be positive");
+    const size_t span = (size_t)(nx + 1) * sx + (size_t)(ny + 1) * sy + (size_t)(nz + 1) * sz + 1;
+    if (int rc = ensure(ctx, ctx->input, span * sizeof(float))) return rc;
+    VTMC_HIP(ctx, hipMemcpyAsync(ctx->input.p, grid, span * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return VTMC_OK;
+}
+
+BlockSpace dense_space(const float *d_base, int nx, int ny, int nz, int64_t sx, int64_t sy, int64_t sz, int n_volumes,
+                       int64_t sv)
+{
+    BlockSpace sp{};
+    sp.base = d_base;
+    sp.sx = sx;
+    sp.sy = sy;
+    sp.sz = sz;
+    sp.sv = sv;
+    sp.nbx = nx / 8;
+    sp.nby = ny / 8;
+    sp.nbz = nz / 8;
+    sp.bpv = sp.nbx * sp.nby * sp.nbz;
+    sp.n_blocks = sp.bpv * n_volumes;
+    sp.list = nullptr;
+    sp.zfast = (sz == 1 && sx != 1) ? 1 : 0;
+    sp.nx = nx;
+    return sp;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vtmc_version(void) { return "vtmc 0.1 gfx950"; }
+
+int32_t vtmc_create(int32_t device, vtmc_ctx **out_ctx)
+{
+    if (!out_ctx) return fail(nullptr, VTMC_ERR_INVALID_ARG, "out_ctx is null");
+    *out_ctx = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(nullptr, VTMC_ERR_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= n_dev) return fail(nullptr, VTMC_ERR_INVALID_ARG, "device %d out of range [0,%d)", device, n_dev);
+    vtmc_ctx *ctx = new (std::nothrow) vtmc_ctx();
+    if (!ctx) return fail(nullptr, VTMC_ERR_DEVICE, "out of host memory");
+    ctx->device = device;
+    auto bail = [&](const char *what, hipError_t err) {
+        std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+        vtmc_destroy(ctx);
+        return fail(nullptr, VTMC_ERR_DEVICE, "%s", msg.c_str());
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (auto &ev : ctx->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipHostMalloc((void **)&ctx->h_totals, 2 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+        return bail("hipHostMalloc", e);
+
+    // tables: VoxelTerrain.cs:151-156 uploads three int tables; here the packed 2 KB vert table and a
+    // 256-byte triangle-count table (the edge-mask table is implied by the vert table)
+    static const unsigned long long packed[VTMC_MC_TABLE_WORDS] = VTMC_MC_TABLE_INIT;
+    unsigned char tri_num[256];
+    for (int c = 0; c < 256; ++c) tri_num[c] = (unsigned char)(packed[c] >> 60);
+    if (ensure(ctx, ctx->d_vert, sizeof packed) || ensure(ctx, ctx->d_trinum, sizeof tri_num)) {
+        std::string msg = ctx->err;
+        vtmc_destroy(ctx);
+        return fail(nullptr, VTMC_ERR_DEVICE, "%s", msg.c_str());
+    }
+    if ((e = hipMemcpy(ctx->d_vert.p, packed, sizeof packed, hipMemcpyHostToDevice)) != hipSuccess) return bail("table upload", e);
+    if ((e = hipMemcpy(ctx->d_trinum.p, tri_num, sizeof tri_num, hipMemcpyHostToDevice)) != hipSuccess) return bail("table upload", e);
+    ctx->tables.vert_packed = (const unsigned long long *)ctx->d_vert.p;
+    ctx->tables.tri_num = (const unsigned char *)ctx->d_trinum.p;
+    *out_ctx = ctx;
+    return VTMC_OK;
+}
+
+int32_t vtmc_destroy(vtmc_ctx *ctx)
+{
+    if (!ctx) return VTMC_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf *b : {&ctx->d_vert, &ctx->d_trinum, &ctx->counts, &ctx->offsets, &ctx->active, &ctx->partials, &ctx->totals,
+                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins})
+        release(*b);
+    if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
+    for (auto &ev : ctx->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VTMC_OK;
+}
+
+const char *vtmc_last_error(const vtmc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int32_t vtmc_extract_blocks(vtmc_ctx *ctx, const float *samples, int32_t n_blocks, int32_t *tri_count)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (n_blocks < 0 || (n_blocks > 0 && !samples)) return fail(ctx, VTMC_ERR_INVALID_ARG, "samples is null or n_blocks < 0");
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)n_blocks * VTMC_TILE_SAMPLES * sizeof(float);
+    if (n_blocks > 0) {
+        if (int rc = ensure(ctx, ctx->input, bytes)) return rc;
+        VTMC_HIP(ctx, hipMemcpyAsync(ctx->input.p, samples, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    // the tile buffer is a batch of n_blocks volumes of one 8^3 block each
+    BlockSpace sp = dense_space((const float *)ctx->input.p, 8, 8, 8, 1, 10, 100, n_blocks, VTMC_TILE_SAMPLES);
+    int64_t T = 0;
+    if (int rc = extract_core(ctx, sp, 0, 0, ctx->stream, &T)) return rc;
+    if (tri_count) *tri_count = (int32_t)T;
+    return VTMC_OK;
+}
+
+int32_t vtmc_extract_grid(vtmc_ctx *ctx, const float *grid, int32_t nx, int32_t ny, int32_t nz, int64_t stride_x,
+                          int64_t stride_y, int64_t stride_z, const int32_t *block_list, int32_t n_blocks,
+                          int32_t *tri_count)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!grid) return fail(ctx, VTMC_ERR_INVALID_ARG, "grid is null");
+    if (int rc = check_dims(ctx, nx, ny, nz)) return rc;
+    if (block_list && n_blocks < 0) return fail(ctx, VTMC_ERR_INVALID_ARG, "n_blocks < 0");
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    BlockSpace sp = dense_space(nullptr, nx, ny, nz, stride_x, stride_y, stride_z, 1, 0);
+    if (block_list) {
+        for (int32_t b = 0; b < n_blocks; ++b) {
+            const int32_t *p = block_list + 3 * (size_t)b;
+            if (p[0] < 0 || p[0] >= sp.nbx || p[1] < 0 || p[1] >= sp.nby || p[2] < 0 || p[2] >= sp.nbz)
+                return fail(ctx, VTMC_ERR_DIMS, "block %d = (%d,%d,%d) outside the %dx%dx%d block grid", b, p[0], p[1], p[2],
+                            sp.nbx, sp.nby, sp.nbz);
+        }
+        const size_t span = (size_t)(nx + 1) * stride_x + (size_t)(ny + 1) * stride_y + (size_t)(nz + 1) * stride_z + 1;
+        if ((size_t)n_blocks * VTMC_TILE_SAMPLES * 2 < span) {
+            // small dirty set on a large grid: gather tiles on the host exactly as BatchUpdate does
+            // (VoxelTerrain.cs:341-361) so only B*4000 bytes cross PCIe instead of the whole grid
+            if (stride_x <= 0 || stride_y <= 0 || stride_z <= 0) return fail(ctx, VTMC_ERR_INVALID_ARG, "strides must be positive");
+            std::vector<float> tiles((size_t)n_blocks * VTMC_TILE_SAMPLES);
+            for (int32_t b = 0; b < n_blocks; ++b) {
+                const int32_t *p = block_list + 3 * (size_t)b;
+                const float *org = grid + 8 * ((int64_t)p[0] * stride_x + (int64_t)p[1] * stride_y + (int64_t)p[2] * stride_z);
+                float *t = tiles.data() + (size_t)b * VTMC_TILE_SAMPLES;
+                for (int iz = 0; iz < 10; ++iz)
+                    for (int iy = 0; iy < 10; ++iy)
+                        for (int ix = 0; ix < 10; ++ix) t[ix + 10 * iy + 100 * iz] = org[ix * stride_x + iy * stride_y + iz * stride_z];
+            }
+            return vtmc_extract_blocks(ctx, tiles.data(), n_blocks, tri_count);
+        }
+        if (int rc = upload_grid(ctx, grid, nx, ny, nz, stride_x, stride_y, stride_z)) return rc;
+        if (int rc = ensure(ctx, ctx->list, sizeof(int32_t) * 3 * (size_t)std::max(n_blocks, 1))) return rc;
+        if (n_blocks > 0)
+            VTMC_HIP(ctx, hipMemcpyAsync(ctx->list.p, block_list, sizeof(int32_t) * 3 * (size_t)n_blocks, hipMemcpyHostToDevice, ctx->stream));
+        sp.list = (const int *)ctx->list.p;
+        sp.n_blocks = n_blocks;
+    } else {
+        if (int rc = upload_grid(ctx, grid, nx, ny, nz, stride_x, stride_y, stride_z)) return rc;
+    }
+    sp.base = (const float *)ctx->input.p;
+    int64_t T = 0;
+    if (int rc = extract_core(ctx, sp, block_list ? 0 : 1, 0, ctx->stream, &T)) return rc;
+    if (tri_count) *tri_count = (int32_t)T;
+    return VTMC_OK;
+}
+
+int32_t vtmc_extract_grid_sharded(vtmc_ctx *ctx, const float *grid, int32_t nx, int32_t ny, int32_t nz, int64_t stride_x,
+                                  int64_t stride_y, int64_t stride_z, int32_t chunk_cells, int32_t rank, int32_t world_size,
+                                  uint32_t *chunk_counts, int32_t chunk_counts_capacity, int32_t *n_local_chunks,
+                                  int32_t *tri_count)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!grid) return fail(ctx, VTMC_ERR_INVALID_ARG, "grid is null");
+    if (int rc = check_dims(ctx, nx, ny, nz)) return rc;
+    if (chunk_cells <= 0 || chunk_cells % 8 || nx % chunk_cells || ny % chunk_cells || nz % chunk_cells)
+        return fail(ctx, VTMC_ERR_DIMS, "chunk size %d must be a multiple of 8 dividing %dx%dx%d", chunk_cells, nx, ny, nz);
+    if (world_size <= 0 || rank < 0 || rank >= world_size) return fail(ctx, VTMC_ERR_INVALID_ARG, "bad rank %d / world %d", rank, world_size);
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    const int ncx = nx / chunk_cells, ncy = ny / chunk_cells, ncz = nz / chunk_cells;
+    const int cb = chunk_cells / 8, bpc = cb * cb * cb;
+    std::vector<int32_t> list;
+    int n_local = 0;
+    for (int c = 0; c < ncx * ncy * ncz; ++c) {
+        if (c % world_size != rank) continue;
+        const int cx = c % ncx, cy = (c / ncx) % ncy, cz = c / (ncx * ncy);
+        for (int bz = 0; bz < cb; ++bz)
+            for (int by = 0; by < cb; ++by)
+                for (int bx = 0; bx < cb; ++bx) {
+                    list.push_back(cx * cb + bx);
+                    list.push_back(cy * cb + by);
+                    list.push_back(cz * cb + bz);
+                }
+        ++n_local;
+    }
+    if (n_local_chunks) *n_local_chunks = n_local;
+    if (chunk_counts && chunk_counts_capacity < n_local)
+        return fail(ctx, VTMC_ERR_CAPACITY, "chunk_counts holds %d chunks, need %d", chunk_counts_capacity, n_local);
+    if (int rc = upload_grid(ctx, grid, nx, ny, nz, stride_x, stride_y, stride_z)) return rc;
+    const int n_blocks = n_local * bpc;
+    if (int rc = ensure(ctx, ctx->list, sizeof(int32_t) * 3 * (size_t)std::max(n_blocks, 1))) return rc;
+    if (n_blocks > 0)
+        VTMC_HIP(ctx, hipMemcpyAsync(ctx->list.p, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice, ctx->stream));
+    BlockSpace sp = dense_space((const float *)ctx->input.p, nx, ny, nz, stride_x, stride_y, stride_z, 1, 0);
+    sp.list = (const int *)ctx->list.p;
+    sp.n_blocks = n_blocks;
+    sp.bpv = bpc;  // chunk-major list: each local chunk is a contiguous run of bpc blocks
+    int64_t T = 0;
+    if (int rc = extract_core(ctx, sp, n_local, 0, ctx->stream, &T)) return rc;
+    if (chunk_counts && n_local > 0) {
+        if (n_blocks > 0)
+            VTMC_HIP(ctx, hipMemcpy(chunk_counts, ctx->volcounts.p, sizeof(uint32_t) * 2 * (size_t)n_local, hipMemcpyDeviceToHost));
+    }
+    if (tri_count) *tri_count = (int32_t)T;
+    return VTMC_OK;
+}
+
+int32_t vtmc_read_triangles(vtmc_ctx *ctx, vtmc_triangle *dst, int64_t capacity, int32_t *block_tri_offsets)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->has_result) return fail(ctx, VTMC_ERR_NO_RESULT, "read_triangles before any extract");
+    if (capacity < ctx->last_tris) return fail(ctx, VTMC_ERR_CAPACITY, "capacity %lld < %lld triangles", (long long)capacity, (long long)ctx->last_tris);
+    if (ctx->last_tris > 0 && !dst) return fail(ctx, VTMC_ERR_INVALID_ARG, "dst is null");
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->last_tris > 0)
+        VTMC_HIP(ctx, hipMemcpy(dst, ctx->tris.p, sizeof(vtmc_triangle) * (size_t)ctx->last_tris, hipMemcpyDeviceToHost));
+    if (block_tri_offsets) {
+        if (ctx->last_blocks > 0)
+            VTMC_HIP(ctx, hipMemcpy(block_tri_offsets, ctx->offsets.p, sizeof(uint32_t) * ((size_t)ctx->last_blocks + 1), hipMemcpyDeviceToHost));
+        else block_tri_offsets[0] = 0;
+    }
+    return VTMC_OK;
+}
+
+int32_t vtmc_read_cases(vtmc_ctx *ctx, uint8_t *dst, int64_t capacity)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->has_result) return fail(ctx, VTMC_ERR_NO_RESULT, "read_cases before any extract");
+    const int64_t need = (int64_t)ctx->last_blocks * 512;
+    if (capacity < need) return fail(ctx, VTMC_ERR_CAPACITY, "capacity %lld < %lld bytes", (long long)capacity, (long long)need);
+    if (need == 0) return VTMC_OK;
+    if (!dst) return fail(ctx, VTMC_ERR_INVALID_ARG, "dst is null");
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    // materialise _CornerFlags on demand with the per-block classify kernel (the input of the last
+    // extract is still resident: ctx-owned for host entry points, caller-owned for device ones)
+    if (int rc = ensure(ctx, ctx->cases, (size_t)need)) return rc;
+    DevBuf tmp;
+    if (int rc = ensure(ctx, tmp, sizeof(uint32_t) * (size_t)ctx->last_blocks)) return rc;
+    hipError_t e = launch_classify_blocks(ctx->last_space, ctx->tables, (uint32_t *)tmp.p, (uint8_t *)ctx->cases.p, ctx->n_cus, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(dst, ctx->cases.p, (size_t)need, hipMemcpyDeviceToHost);
+    release(tmp);
+    if (e != hipSuccess) return fail(ctx, VTMC_ERR_DEVICE, "read_cases: %s", hipGetErrorString(e));
+    return VTMC_OK;
+}
+
+int32_t vtmc_last_counts(const vtmc_ctx *ctx, int32_t *n_blocks, int32_t *tri_count)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->has_result) return VTMC_ERR_NO_RESULT;
+    if (n_blocks) *n_blocks = ctx->last_blocks;
+    if (tri_count) *tri_count = (int32_t)ctx->last_tris;
+    return VTMC_OK;
+}
+
+int32_t vtmc_extract_volumes_device(vtmc_ctx *ctx, const vtmc_volume_batch *batch, void *stream, uint32_t flags,
+                                    int64_t *tri_count)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!batch || !batch->d_samples) return fail(ctx, VTMC_ERR_INVALID_ARG, "batch or batch->d_samples is null");
+    if (int rc = check_dims(ctx, batch->nx, batch->ny, batch->nz)) return rc;
+    if (batch->n_volumes < 0) return fail(ctx, VTMC_ERR_INVALID_ARG, "n_volumes < 0");
+    if (batch->stride_x <= 0 || batch->stride_y <= 0 || batch->stride_z <= 0 || batch->volume_stride < 0)
+        return fail(ctx, VTMC_ERR_INVALID_ARG, "strides must be positive");
+    const long long bpv = (long long)(batch->nx / 8) * (batch->ny / 8) * (batch->nz / 8);
+    if (bpv * batch->n_volumes > 0x7fffffffll) return fail(ctx, VTMC_ERR_TOO_LARGE, "more than 2^31-1 blocks");
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    BlockSpace sp = dense_space(batch->d_samples, batch->nx, batch->ny, batch->nz, batch->stride_x, batch->stride_y,
+                                batch->stride_z, batch->n_volumes, batch->volume_stride);
+    return extract_core(ctx, sp, batch->n_volumes, flags, stream ? (hipStream_t)stream : ctx->stream, tri_count);
+}
+
+int32_t vtmc_device_results(vtmc_ctx *ctx, const vtmc_triangle **d_triangles, const uint32_t **d_block_tri_offsets,
+                            const uint32_t **d_volume_counts)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->has_result) return fail(ctx, VTMC_ERR_NO_RESULT, "device_results before any extract");
+    if (d_triangles) *d_triangles = (const vtmc_triangle *)ctx->tris.p;
+    if (d_block_tri_offsets) *d_block_tri_offsets = (const uint32_t *)ctx->offsets.p;
+    if (d_volume_counts) *d_volume_counts = (const uint32_t *)ctx->volcounts.p;
+    return VTMC_OK;
+}
+
+int32_t vtmc_reserve_triangles(vtmc_ctx *ctx, int64_t capacity)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (capacity < 0 || capacity > 0x7fffffffll) return fail(ctx, VTMC_ERR_INVALID_ARG, "capacity out of range");
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->has_result = false;  // the old triangle buffer may be released
+    return ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * (size_t)std::max<int64_t>(capacity, 1));
+}
+
+int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4])
+{
+    if (!ctx || !ms) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->has_result) return fail(ctx, VTMC_ERR_NO_RESULT, "last_stage_ms before any extract");
+    memcpy(ms, ctx->stage_ms, sizeof ctx->stage_ms);
+    return VTMC_OK;
+}
+
+int32_t vtmc_density_fill_device(vtmc_ctx *ctx, const vtmc_density_params *params, const int32_t *origins, int32_t n_volumes,
+                                 int32_t dim_x, int32_t dim_y, int32_t dim_z, int64_t stride_x, int64_t stride_y,
+                                 int64_t stride_z, int64_t volume_stride, float *d_out, void *stream)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!params || !origins || !d_out) return fail(ctx, VTMC_ERR_INVALID_ARG, "null argument");
+    if (n_volumes <= 0 || dim_x <= 0 || dim_y <= 0 || dim_z <= 0 || params->octaves < 1 || params->octaves > 16)
+        return fail(ctx, VTMC_ERR_INVALID_ARG, "bad volume count, dims or octaves");
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (!ctx->perm_valid || ctx->perm_seed != params->seed) {
+        unsigned char perm[256];
+        density_permutation(params->seed, perm);
+        if (int rc = ensure(ctx, ctx->perm, 256)) return rc;
+        VTMC_HIP(ctx, hipMemcpy(ctx->perm.p, perm, 256, hipMemcpyHostToDevice));
+        ctx->perm_seed = params->seed;
+        ctx->perm_valid = true;
+    }
+    if (int rc = ensure(ctx, ctx->origins, sizeof(int32_t) * 3 * (size_t)n_volumes)) return rc;
+    VTMC_HIP(ctx, hipMemcpy(ctx->origins.p, origins, sizeof(int32_t) * 3 * (size_t)n_volumes, hipMemcpyHostToDevice));
+    DensityLaunch dl{};
+    dl.frequency = params->frequency;
+    dl.lacunarity = params->lacunarity;
+    dl.gain = params->gain;
+    dl.ramp_scale = params->ramp_scale;
+    dl.ramp_center = params->ramp_center;
+    dl.octaves = params->octaves;
+    dl.dx = dim_x;
+    dl.dy = dim_y;
+    dl.dz = dim_z;
+    dl.sx = stride_x;
+    dl.sy = stride_y;
+    dl.sz = stride_z;
+    dl.sv = volume_stride;
+    dl.n_volumes = n_volumes;
+    VTMC_HIP(ctx, launch_density(dl, (const unsigned char *)ctx->perm.p, (const int *)ctx->origins.p, d_out, st));
+    VTMC_HIP(ctx, hipStreamSynchronize(st));
+    return VTMC_OK;
+}
+
+}  // extern "C"

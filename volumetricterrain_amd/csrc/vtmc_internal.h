@@ -1,0 +1,57 @@
+// vtmc_internal.h -- shared between the HIP kernels and the C-ABI host layer (not installed).
+#ifndef VTMC_INTERNAL_H
+#define VTMC_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vtmc {
+
+// How kernels find the 10x10x10 sample tile of block b.
+//  dense: b = v*bpv + bx + nbx*(by + nby*bz)  -> origin = v*sv + 8*(bx*sx + by*sy + bz*sz)
+//  list : (bx,by,bz) = list[3b..3b+2] (the dirty list, VoxelTerrain.cs:321), single volume
+struct BlockSpace {
+    const float *base;
+    long long sx, sy, sz, sv;  // element strides
+    int nbx, nby, nbz;         // blocks per volume
+    int bpv;                   // nbx*nby*nbz
+    int n_blocks;              // total blocks submitted
+    const int *list;           // device, n_blocks x 3, or nullptr
+    int zfast;                 // sz == 1: tile loads walk z fastest (C# float[,,] layout)
+    int nx;                    // cells along x per volume (dense classify)
+};
+
+struct DeviceTables {
+    const unsigned long long *vert_packed;  // 256 x u64 (mc_tables_packed.h)
+    const unsigned char *tri_num;           // 256 x u8
+};
+
+// scan scratch layout
+constexpr int kScanTile = 2048;  // block counts per scan workgroup (256 threads x 8)
+
+// Launch wrappers (mc_kernels.hip).  All asynchronous on `stream`; return hipGetLastError().
+hipError_t launch_classify_blocks(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
+                                  uint8_t *cases_or_null, int n_cus, hipStream_t stream);
+hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
+                                 hipStream_t stream);
+hipError_t launch_scan(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list,
+                       uint32_t *partials, uint32_t *totals, int bpv, int n_volumes,
+                       uint32_t *volume_counts, hipStream_t stream);
+hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets,
+                       const int32_t *active_list, const uint32_t *totals, uint32_t capacity,
+                       void *triangles, int n_cus, hipStream_t stream);
+
+// density.hip
+struct DensityLaunch {
+    float frequency, lacunarity, gain, ramp_scale, ramp_center;
+    int octaves;
+    int dx, dy, dz;
+    long long sx, sy, sz, sv;
+    int n_volumes;
+};
+hipError_t launch_density(const DensityLaunch &dl, const unsigned char *d_perm, const int *d_origins,
+                          float *d_out, hipStream_t stream);
+void density_permutation(uint64_t seed, unsigned char perm[256]);
+
+}  // namespace vtmc
+#endif

@@ -1,0 +1,147 @@
+"""Extractor -- thin Python owner of one vtmc context (one per GPU / process).
+
+Mirrors the call sequence of VoxelTerrain.BatchUpdate (VoxelTerrain.cs:365-427):
+extract_* (upload + three dispatches + count read-back) then read_triangles (GetData).
+numpy arrays stand in for the pinned C# arrays; nothing here computes -- every result
+comes out of libvtmc.so.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import TRI_DTYPE, DensityParams, VolumeBatch, VtmcError
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def elem_strides(grid):
+    if grid.dtype != np.float32 or grid.ndim != 3:
+        raise ValueError("grid must be a 3-D float32 array indexed [x, y, z]")
+    if any(s % 4 for s in grid.strides):
+        raise ValueError("grid strides must be multiples of 4 bytes")
+    return tuple(int(s) // 4 for s in grid.strides)
+
+
+def density_params(kind, n, seed=1337):
+    """perlin3d f = 8/N; fbm8 = 8 octaves, lacunarity 2, gain 0.5, f = 4/N, minus a ramp."""
+    if kind == "perlin3d":
+        return DensityParams(seed, 8.0 / n, 1, 2.0, 0.5, 0.0, 0.0)
+    if kind == "fbm8":
+        return DensityParams(seed, 4.0 / n, 8, 2.0, 0.5, 2.0 / n, n / 2.0)
+    raise ValueError("unknown density kind %r" % (kind,))
+
+
+class Extractor:
+    def __init__(self, device=0):
+        self._L = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self._L.vtmc_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise VtmcError(rc, self._L.vtmc_last_error(None).decode())
+        self._h = h
+        self.device = device
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise VtmcError(rc, self._L.vtmc_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vtmc_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host entry points (what the C# shim P/Invokes) --------------------------------------
+    def extract_blocks(self, samples):
+        """samples: (B, 1000) float32 tiles laid out as VoxelTerrain.cs:341-361.  Returns T."""
+        samples = np.ascontiguousarray(samples, np.float32).reshape(-1, 1000)
+        t = ctypes.c_int32()
+        self._check(self._L.vtmc_extract_blocks(self._h, _ptr(samples), samples.shape[0], ctypes.byref(t)))
+        return t.value
+
+    def extract_grid(self, grid, block_list=None):
+        """grid indexed [x, y, z], shape (nx+2, ny+2, nz+2), any positive strides.  Returns T."""
+        sx, sy, sz = elem_strides(grid)
+        nx, ny, nz = (d - 2 for d in grid.shape)
+        n = 0
+        if block_list is not None:
+            block_list = np.ascontiguousarray(block_list, np.int32).reshape(-1, 3)
+            n = len(block_list)
+        t = ctypes.c_int32()
+        self._check(self._L.vtmc_extract_grid(self._h, _ptr(grid), nx, ny, nz, sx, sy, sz,
+                                              _ptr(block_list), n, ctypes.byref(t)))
+        return t.value
+
+    def extract_grid_sharded(self, grid, chunk_cells, rank, world_size):
+        """Returns (T_local, chunk_counts[n_local, 2] = {vertices, triangles})."""
+        sx, sy, sz = elem_strides(grid)
+        nx, ny, nz = (d - 2 for d in grid.shape)
+        n_chunks = max(1, (nx // chunk_cells) * (ny // chunk_cells) * (nz // chunk_cells)) if chunk_cells > 0 else 1
+        counts = np.zeros((n_chunks, 2), np.uint32)
+        n_local, t = ctypes.c_int32(), ctypes.c_int32()
+        self._check(self._L.vtmc_extract_grid_sharded(self._h, _ptr(grid), nx, ny, nz, sx, sy, sz,
+                                                      chunk_cells, rank, world_size, _ptr(counts),
+                                                      n_chunks, ctypes.byref(n_local), ctypes.byref(t)))
+        return t.value, counts[:n_local.value].copy()
+
+    def last_counts(self):
+        b, t = ctypes.c_int32(), ctypes.c_int32()
+        self._check(self._L.vtmc_last_counts(self._h, ctypes.byref(b), ctypes.byref(t)))
+        return b.value, t.value
+
+    def read_triangles(self, with_offsets=True):
+        n_blocks, n_tris = self.last_counts()
+        tris = np.zeros(n_tris, TRI_DTYPE)
+        offs = np.zeros(n_blocks + 1, np.int32) if with_offsets else None
+        self._check(self._L.vtmc_read_triangles(self._h, _ptr(tris), n_tris, _ptr(offs)))
+        return (tris, offs) if with_offsets else tris
+
+    def read_cases(self):
+        n_blocks, _ = self.last_counts()
+        cases = np.zeros((n_blocks, 512), np.uint8)
+        self._check(self._L.vtmc_read_cases(self._h, _ptr(cases), cases.nbytes))
+        return cases
+
+    # -- device-resident entry points ---------------------------------------------------------
+    def extract_volumes_device(self, d_ptr, n, strides, n_volumes=1, volume_stride=0, stream=None, flags=0):
+        """d_ptr: device address (int) of the first sample; n = (nx, ny, nz) cells per volume;
+        strides = element strides (sx, sy, sz).  Returns T."""
+        vb = VolumeBatch(d_ptr, n[0], n[1], n[2], strides[0], strides[1], strides[2], n_volumes, volume_stride)
+        t = ctypes.c_int64()
+        self._check(self._L.vtmc_extract_volumes_device(self._h, ctypes.byref(vb), stream, flags, ctypes.byref(t)))
+        return t.value
+
+    def device_results(self):
+        """(triangles, block_tri_offsets, volume_counts) device addresses of the last extract."""
+        a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self._L.vtmc_device_results(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    def reserve_triangles(self, capacity):
+        self._check(self._L.vtmc_reserve_triangles(self._h, int(capacity)))
+
+    def last_stage_ms(self):
+        ms = (ctypes.c_float * 4)()
+        self._check(self._L.vtmc_last_stage_ms(self._h, ctypes.byref(ms)))
+        return {"classify": ms[0], "scan": ms[1], "emit": ms[2], "total": ms[3]}
+
+    def density_fill_device(self, params, origins, dims, strides, volume_stride, d_out, stream=None):
+        origins = np.ascontiguousarray(origins, np.int32).reshape(-1, 3)
+        self._check(self._L.vtmc_density_fill_device(self._h, ctypes.byref(params), _ptr(origins), len(origins),
+                                                     dims[0], dims[1], dims[2], strides[0], strides[1],
+                                                     strides[2], volume_stride, d_out, stream))
