@@ -143,6 +143,11 @@ int32_t vtmc_reserve_triangles(vtmc_ctx *ctx, int64_t capacity);
  * The reference's only timing hook is the commented-out timer at VoxelTerrain.cs:363/467. */
 int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4]);
 
+/* Diagnostics: select a kernel variant / launch shape for A/B measurements in one process
+ * (keys: "emit_version", "emit_fast_math", "emit_wgs_per_cu").  Results stay
+ * within the parity bar for every setting; defaults are the shipped configuration. */
+int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value);
+
 /* Synthetic density sampler (the reference has no noise field of its own):
  * density = sum_{o<octaves} gain^o * perlin(p*frequency*lacunarity^o) - (p.y - ramp_center)*ramp_scale,
  * p = volume origin + sample index, FP32, Perlin 2002 improved noise with a SplitMix64 permutation. */

@@ -38,6 +38,51 @@ def assert_tris_match(got, want, atol=ATOL):
     return worst
 
 
+def test_exact_mode_is_bit_compatible_with_oracle(ex, oracle_mod):
+    """emit_fast_math=0: correctly rounded divide / sqrt, contraction off => identical floats
+    (up to the sign of zero); both emit kernel generations.  The shipped default (v_rcp / v_rsq)
+    stays within ATOL and is what every other test runs."""
+    g = oracle_mod.density_volume("perlin3d", 64)
+    want, want_offs, _ = oracle_mod.extract_grid(g, threads=8)
+    try:
+        for version in (2, 1):
+            ex.set_tuning(emit_fast_math=0, emit_version=version)
+            assert ex.extract_grid(g) == len(want)
+            got, offs = ex.read_triangles()
+            assert np.array_equal(offs, want_offs)
+            assert assert_tris_match(got, want, atol=0.0) == 0.0
+        ex.set_tuning(emit_fast_math=1, emit_version=1)
+        assert ex.extract_grid(g) == len(want)
+        assert_tris_match(ex.read_triangles(False), want)
+    finally:
+        ex.set_tuning(emit_fast_math=1, emit_version=2)
+    assert ex.extract_grid(g) == len(want)
+    worst = assert_tris_match(ex.read_triangles(False), want)
+    assert worst <= 2e-6, worst     # fast path: observed ~5e-7, bar 1e-5
+
+
+def test_exact_zero_samples_and_unit_weights(ex, oracle_mod):
+    """Samples that are exactly 0 give t = -0 / t = 1 (vertices ON lattice points).  A 1-ulp
+    reciprocal must not step floor/ceil past the edge (regression: garbage lattice reads turned a
+    zero-weight normal into NaN).  The v1 kernel runs first so LDS holds foreign leftovers."""
+    rng = np.random.default_rng(11)
+    n = (32, 32, 32)
+    g = fields.random_field(n, seed=3)
+    ints = rng.integers(-2, 3, size=g.shape).astype(np.float32)
+    g[...] = np.where(rng.random(g.shape) < 0.5, ints, g)      # half the samples are small integers, many 0
+    want, want_offs, _ = oracle_mod.extract_grid(g, threads=8)
+    try:
+        ex.set_tuning(emit_version=1, emit_fast_math=0)
+        ex.extract_grid(g)
+    finally:
+        ex.set_tuning(emit_version=2, emit_fast_math=1)
+    for _ in range(2):
+        assert ex.extract_grid(g) == len(want)
+        got, offs = ex.read_triangles()
+        assert np.array_equal(offs, want_offs)
+        assert_tris_match(got, want)
+
+
 def test_tile_batch_matches_oracle(ex, oracle_mod):
     """vtmc_extract_blocks on the reference's own tile layout (VoxelTerrain.cs:341-361)."""
     g = oracle_mod.density_volume("perlin3d", 32)

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""A/B harness: interleaved rounds of kernel variants in ONE process on the bench workload
+(cdna_hip_programming.md rule 24).  Prints median / min per stage for each variant.
+
+    python tools/ab_bench.py "emit_assign=0" "emit_assign=1" "emit_assign=1,emit_wide_store=0" --rounds 7
+"""
+import argparse
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("variants", nargs="+", help="comma-separated key=value tuning sets; 'base' = defaults")
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--n", type=int, default=1024)
+    ap.add_argument("--chunk", type=int, default=128)
+    ap.add_argument("--kind", default="perlin3d")
+    ap.add_argument("--flags", type=int, default=0)
+    args = ap.parse_args()
+    import torch
+    import volumetricterrain_amd as vt
+    from volumetricterrain_amd import sharding
+
+    n, c = args.n, args.chunk
+    dim = c + 2
+    origins = sharding.chunk_origins(n, c)
+    ex = vt.Extractor(0)
+    d = torch.empty(len(origins) * dim ** 3, dtype=torch.float32, device="cuda")
+    ex.density_fill_device(vt.density_params(args.kind, n), origins, (dim, dim, dim), (1, dim, dim * dim), dim ** 3,
+                           d.data_ptr())
+    defaults = dict(emit_version=2, emit_fast_math=1, emit_wgs_per_cu=3)
+
+    def apply(spec):
+        kv = dict(defaults)
+        if spec != "base":
+            for item in spec.split(","):
+                k, v = item.split("=")
+                kv[k] = int(v)
+        ex.set_tuning(**kv)
+
+    def run():
+        T = ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), len(origins), dim ** 3,
+                                      None, args.flags)
+        return T, ex.last_stage_ms()
+
+    apply("base")
+    for _ in range(2):
+        run()
+    res = {v: {"classify": [], "scan": [], "emit": [], "total": []} for v in args.variants}
+    for _ in range(args.rounds):
+        for v in args.variants:
+            apply(v)
+            T, ms = run()
+            for k in res[v]:
+                res[v][k].append(ms[k])
+    print("T =", T)
+    for v in args.variants:
+        print("%-48s" % v, "  ".join("%s med %.4f min %.4f" % (k, statistics.median(x), min(x)) for k, x in res[v].items()))
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,7 @@ SYMBOLS = [
     "vtmc_version", "vtmc_create", "vtmc_destroy", "vtmc_last_error", "vtmc_extract_blocks",
     "vtmc_extract_grid", "vtmc_extract_grid_sharded", "vtmc_read_triangles", "vtmc_read_cases",
     "vtmc_last_counts", "vtmc_extract_volumes_device", "vtmc_device_results",
-    "vtmc_reserve_triangles", "vtmc_last_stage_ms", "vtmc_density_fill_device",
+    "vtmc_reserve_triangles", "vtmc_last_stage_ms", "vtmc_set_tuning", "vtmc_density_fill_device",
 ]
 
 
@@ -76,6 +76,7 @@ def load():
     L.vtmc_device_results.argtypes = [vp, P(vp), P(vp), P(vp)]
     L.vtmc_reserve_triangles.argtypes = [vp, i64]
     L.vtmc_last_stage_ms.argtypes = [vp, P(ctypes.c_float * 4)]
+    L.vtmc_set_tuning.argtypes = [vp, ctypes.c_char_p, i32]
     L.vtmc_density_fill_device.argtypes = [vp, P(DensityParams), vp, i32, i32, i32, i32,
                                            i64, i64, i64, i64, vp, vp]
     for name in SYMBOLS:

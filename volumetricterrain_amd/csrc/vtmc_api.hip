@@ -51,6 +51,7 @@ struct vtmc_ctx {
     int last_blocks = 0;
     int last_volumes = 0;
     int64_t last_tris = 0;
+    Tuning tune;
     uint64_t perm_seed = 0;
     bool perm_valid = false;
     std::string err;
@@ -117,6 +118,9 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
         if (tri_count) *tri_count = 0;
         return VTMC_OK;
     }
+    // the emit kernel addresses a tile with 32-bit byte offsets from the block origin
+    if ((9.0 * ((double)sp.sx + (double)sp.sy + (double)sp.sz) + 1.0) * 4.0 >= 4294967296.0)
+        return fail(ctx, VTMC_ERR_TOO_LARGE, "strides too large: a 10x10x10 tile must span less than 4 GiB");
     const int n_tiles = (B + kScanTile - 1) / kScanTile;
     if (int rc = ensure(ctx, ctx->counts, sizeof(uint32_t) * (size_t)B)) return rc;
     if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
@@ -146,7 +150,7 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
     for (int attempt = 0; attempt < 2; ++attempt) {
         const size_t cap = std::min<size_t>(ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
         VTMC_HIP(ctx, launch_emit(sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const int32_t *)ctx->active.p,
-                                  (const uint32_t *)ctx->totals.p, (uint32_t)cap, ctx->tris.p, ctx->n_cus, stream));
+                                  (const uint32_t *)ctx->totals.p, (uint32_t)cap, ctx->tris.p, ctx->n_cus, ctx->tune, stream));
         VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
         VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->totals.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         VTMC_HIP(ctx, hipStreamSynchronize(stream));
@@ -493,6 +497,17 @@ int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4])
     if (!ctx || !ms) return VTMC_ERR_INVALID_ARG;
     if (!ctx->has_result) return fail(ctx, VTMC_ERR_NO_RESULT, "last_stage_ms before any extract");
     memcpy(ms, ctx->stage_ms, sizeof ctx->stage_ms);
+    return VTMC_OK;
+}
+
+int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
+{
+    if (!ctx || !key) return VTMC_ERR_INVALID_ARG;
+    const std::string k(key);
+    if (k == "emit_version") ctx->tune.emit_version = value;
+    else if (k == "emit_fast_math") ctx->tune.emit_fast_math = value;
+    else if (k == "emit_wgs_per_cu") ctx->tune.emit_wgs_per_cu = value;
+    else return fail(ctx, VTMC_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
     return VTMC_OK;
 }
 

@@ -26,6 +26,13 @@ struct DeviceTables {
     const unsigned char *tri_num;           // 256 x u8
 };
 
+// A/B knobs (vtmc_set_tuning); defaults are the shipped configuration.
+struct Tuning {
+    int emit_version = 2;     // 1: first-round kernel (kept for A/B), 2: prefetching / compacting kernel
+    int emit_fast_math = 1;   // 1: v_rcp/v_rsq (<= ~5e-7 from exact); 0: correctly rounded, bit-compatible with the oracle
+    int emit_wgs_per_cu = 3;
+};
+
 // scan scratch layout
 constexpr int kScanTile = 2048;  // block counts per scan workgroup (256 threads x 8)
 
@@ -39,7 +46,7 @@ hipError_t launch_scan(const uint32_t *counts, int n_blocks, uint32_t *offsets, 
                        uint32_t *volume_counts, hipStream_t stream);
 hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets,
                        const int32_t *active_list, const uint32_t *totals, uint32_t capacity,
-                       void *triangles, int n_cus, hipStream_t stream);
+                       void *triangles, int n_cus, const Tuning &tune, hipStream_t stream);
 
 // density.hip
 struct DensityLaunch {

@@ -140,6 +140,10 @@ class Extractor:
         self._check(self._L.vtmc_last_stage_ms(self._h, ctypes.byref(ms)))
         return {"classify": ms[0], "scan": ms[1], "emit": ms[2], "total": ms[3]}
 
+    def set_tuning(self, **kv):
+        for k, v in kv.items():
+            self._check(self._L.vtmc_set_tuning(self._h, k.encode(), int(v)))
+
     def density_fill_device(self, params, origins, dims, strides, volume_stride, d_out, stream=None):
         origins = np.ascontiguousarray(origins, np.int32).reshape(-1, 3)
         self._check(self._L.vtmc_density_fill_device(self._h, ctypes.byref(params), _ptr(origins), len(origins),
