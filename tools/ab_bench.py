@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=128)
     ap.add_argument("--kind", default="perlin3d")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--limit", type=int, default=0, help="use only the first K chunks")
     args = ap.parse_args()
     import torch
     import volumetricterrain_amd as vt
@@ -29,11 +30,13 @@ def main():
     n, c = args.n, args.chunk
     dim = c + 2
     origins = sharding.chunk_origins(n, c)
+    if args.limit:
+        origins = origins[:args.limit]
     ex = vt.Extractor(0)
     d = torch.empty(len(origins) * dim ** 3, dtype=torch.float32, device="cuda")
     ex.density_fill_device(vt.density_params(args.kind, n), origins, (dim, dim, dim), (1, dim, dim * dim), dim ** 3,
                            d.data_ptr())
-    defaults = dict(emit_version=2, emit_fast_math=1, emit_wgs_per_cu=3)
+    defaults = dict(emit_version=2, emit_fast_math=1, emit_wgs_per_cu=3, emit_group_log2=0)
 
     def apply(spec):
         kv = dict(defaults)

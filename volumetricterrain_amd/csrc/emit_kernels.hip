@@ -291,11 +291,12 @@ __device__ __forceinline__ void emit_flush2(EmitLds2 *L, const u64 *s_vert, cons
         float *gal = out + (d0 - sh);  // 16-byte aligned
         for (int q4 = 4 * lane; q4 < hi; q4 += 256) {
             if (q4 >= lo && q4 + 4 <= hi) {
-                *reinterpret_cast<float4 *>(gal + q4) = *reinterpret_cast<const float4 *>(L->stage + q4);
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(*reinterpret_cast<const v4f *>(L->stage + q4), reinterpret_cast<v4f *>(gal + q4));
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (q4 + k >= lo && q4 + k < hi) gal[q4 + k] = L->stage[q4 + k];
+                    if (q4 + k >= lo && q4 + k < hi) __builtin_nontemporal_store(L->stage[q4 + k], gal + q4 + k);
             }
         }
         VTMC_WAVE_SYNC();
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
                                                     const uint32_t *__restrict__ offsets,
                                                     const int32_t *__restrict__ active_list,
                                                     const uint32_t *__restrict__ totals, uint32_t capacity,
-                                                    float *__restrict__ out)
+                                                    float *__restrict__ out, int group_log2)
 {
     __shared__ EmitLds2 s_lds[kWavesPerWg];
     __shared__ u64 s_vert[256];
@@ -356,19 +357,27 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
     // each XCD (blockIdx % 8 under round-robin dispatch; a speed heuristic only) sweeps one
     // contiguous eighth of the active list
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;  // gridDim % 8 == 0
-    int ai = (int)((long long)n_active * xcd / 8) + j * kWavesPerWg + wave;
+    const int ai_begin = (int)((long long)n_active * xcd / 8);
     const int ai_end = (int)((long long)n_active * (xcd + 1) / 8);
-    const int ai_step = per_xcd * kWavesPerWg;
+    // the k-th block of this wave: rounds of (waves per XCD) groups, each wave takes 2^group_log2
+    // consecutive list entries per round (x-adjacent blocks share 128-byte lines)
+    const int u = j * kWavesPerWg + wave, n_u = per_xcd * kWavesPerWg;
+    auto entry = [&](int k) {
+        const int r = k >> group_log2, g = k & ((1 << group_log2) - 1);
+        return ai_begin + (((r * n_u + u) << group_log2) | g);
+    };
 
     float pre[16];
     int b_next = 0;
+    int k = 0;
+    int ai = entry(0);
     if (ai < ai_end) {
         b_next = active_list[ai];
         const char *src = reinterpret_cast<const char *>(sp.base + block_origin(sp, b_next));
 #pragma unroll
         for (int it = 0; it < 16; ++it) pre[it] = *reinterpret_cast<const float *>(src + toff[it]);
     }
-    for (; ai < ai_end; ai += ai_step) {
+    for (; ai < ai_end; ai = entry(++k)) {
         const int b = b_next;
         size_t tri_base = offsets[b];
         // the scan's budget for this block; flushes are clamped to it so a classify/emit mismatch
@@ -377,8 +386,9 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
         VTMC_WAVE_SYNC();
 #pragma unroll
         for (int it = 0; it < 16; ++it) L->tile[tdst[it]] = pre[it];
-        if (ai + ai_step < ai_end) {  // prefetch the next block's tile; it lands while this one is processed
-            b_next = active_list[ai + ai_step];
+        const int ai_next = entry(k + 1);
+        if (ai_next < ai_end) {  // prefetch the next block's tile; it lands while this one is processed
+            b_next = active_list[ai_next];
             const char *src = reinterpret_cast<const char *>(sp.base + block_origin(sp, b_next));
 #pragma unroll
             for (int it = 0; it < 16; ++it) pre[it] = *reinterpret_cast<const float *>(src + toff[it]);
@@ -445,9 +455,9 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
             hipLaunchKernelGGL((emit_v1_kernel<1, false, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o);
     } else {
         if (tune.emit_fast_math)
-            hipLaunchKernelGGL((emit_kernel<true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o);
+            hipLaunchKernelGGL((emit_kernel<true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2);
         else
-            hipLaunchKernelGGL((emit_kernel<false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o);
+            hipLaunchKernelGGL((emit_kernel<false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2);
     }
     return hipGetLastError();
 }

@@ -506,6 +506,7 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     const std::string k(key);
     if (k == "emit_version") ctx->tune.emit_version = value;
     else if (k == "emit_fast_math") ctx->tune.emit_fast_math = value;
+    else if (k == "emit_group_log2") ctx->tune.emit_group_log2 = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (k == "emit_wgs_per_cu") ctx->tune.emit_wgs_per_cu = value;
     else return fail(ctx, VTMC_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
     return VTMC_OK;

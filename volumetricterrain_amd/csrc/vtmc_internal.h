@@ -31,6 +31,7 @@ struct Tuning {
     int emit_version = 2;     // 1: first-round kernel (kept for A/B), 2: prefetching / compacting kernel
     int emit_fast_math = 1;   // 1: v_rcp/v_rsq (<= ~5e-7 from exact); 0: correctly rounded, bit-compatible with the oracle
     int emit_wgs_per_cu = 3;
+    int emit_group_log2 = 0;  // each wave takes 2^g consecutive active-list entries per round
 };
 
 // scan scratch layout
