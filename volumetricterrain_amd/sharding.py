@@ -59,9 +59,10 @@ def allgather_counts(local_counts, group=None):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(local_counts.shape), dtype=local_counts.dtype, device=local_counts.device)
-    dist.all_gather_into_tensor(out, local_counts.contiguous(), group=group)
-    return out
+    flat = local_counts.contiguous().view(-1)
+    out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(out, flat, group=group)   # one collective; flat views suit nccl and gloo alike
+    return out.view((world,) + tuple(local_counts.shape))
 
 
 # -- tiny device -> host copies through the HIP runtime (no torch tensor owns library buffers) ----
