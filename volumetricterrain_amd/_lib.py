@@ -6,6 +6,7 @@ VtmcError (vtmc_create returns VTMC_ERR_DEVICE).
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -57,6 +58,14 @@ def load():
     if _lib is not None:
         return _lib
     path = _build.build()
+    # PyTorch wheels bundle their own libamdhip64; if this process is going to use torch as well
+    # (device memory, streams, torch.distributed), torch must load first so both bind to ONE HIP
+    # runtime -- loaded the other way round torch.cuda reports no device.
+    if "torch" not in sys.modules and os.environ.get("VTMC_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = ctypes.CDLL(path)
     vp, i32, i64, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32
     P = ctypes.POINTER
