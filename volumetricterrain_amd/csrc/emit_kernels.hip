@@ -265,14 +265,14 @@ __device__ __forceinline__ void vertex_on_edge(const float *tile, const unsigned
 
 template <bool FAST>
 __device__ __forceinline__ void emit_flush2(EmitLds2 *L, const u64 *s_vert, const unsigned *s_edge, int pending,
-                                            size_t tri_base, int block_id, float *__restrict__ out, int lane)
+                                            size_t tri_base, int block_id, float *__restrict__ out, int lane, int ablate)
 {
     VTMC_WAVE_SYNC();
     for (int s0 = 0; s0 < pending; s0 += 64) {
         const int s = s0 + lane;
         const size_t d0 = (tri_base + (size_t)s0) * kTriDwords;  // first global dword of this batch
         const int sh = (int)(d0 & 3);                            // staging shift = global misalignment
-        if (s < pending) {
+        if (s < pending && !(ablate & 4)) {
             const unsigned sc = L->slot[s];
             const int cell = sc & 511u, i = sc >> 9;
             const int cx = cell & 7, cy = (cell >> 3) & 7, cz = cell >> 6;
@@ -289,15 +289,33 @@ __device__ __forceinline__ void emit_flush2(EmitLds2 *L, const u64 *s_vert, cons
         const int cnt = pending - s0 < 64 ? pending - s0 : 64;
         const int lo = sh, hi = sh + cnt * kTriDwords;
         float *gal = out + (d0 - sh);  // 16-byte aligned
-        for (int q4 = 4 * lane; q4 < hi; q4 += 256) {
-            if (q4 >= lo && q4 + 4 <= hi) {
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(*reinterpret_cast<const v4f *>(L->stage + q4), reinterpret_cast<v4f *>(gal + q4));
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        // body: whole 16-byte quads, no per-element predicates (write-once stream: non-temporal)
+        const int body_lo = (lo + 3) & ~3, body_hi = hi & ~3;
+        if (!(ablate & 1))
+        if (ablate & 8) {  // experiment: write-through sc1 stores (line dropped from L2)
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            const unsigned long long gaddr = (unsigned long long)gal;
+            const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gaddr), ghi = __builtin_amdgcn_readfirstlane((unsigned)(gaddr >> 32));
+            float *gu = reinterpret_cast<float *>(((unsigned long long)ghi << 32) | glo);
+            auto rsrc = __builtin_amdgcn_make_buffer_rsrc(gu, 0, (64 * kTriDwords + 4) * 4, 0x00020000);
+            if (ablate & 16) {
+                for (int q4 = body_lo + 4 * lane; q4 < body_hi; q4 += 256)
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4i *>(L->stage + q4), rsrc, q4 * 4, 0, 17);
             } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (q4 + k >= lo && q4 + k < hi) __builtin_nontemporal_store(L->stage[q4 + k], gal + q4 + k);
+                for (int q4 = body_lo + 4 * lane; q4 < body_hi; q4 += 256)
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4i *>(L->stage + q4), rsrc, q4 * 4, 0, 16);
             }
+        } else {
+            for (int q4 = body_lo + 4 * lane; q4 < body_hi; q4 += 256)
+                __builtin_nontemporal_store(*reinterpret_cast<const v4f *>(L->stage + q4), reinterpret_cast<v4f *>(gal + q4));
+        }
+        // head (< 4 dwords before the first whole quad) and tail (< 4 after the last): lanes 0-3 / 4-7
+        {
+            const int k = lane & 3;
+            const int idx = lane < 4 ? lo + k : body_hi + k;
+            const bool on = lane < 4 ? (idx < body_lo && idx < hi) : (lane < 8 && idx < hi && idx >= body_lo);
+            if (on) __builtin_nontemporal_store(L->stage[idx], gal + idx);
         }
         VTMC_WAVE_SYNC();
     }
@@ -308,7 +326,7 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
                                                     const uint32_t *__restrict__ offsets,
                                                     const int32_t *__restrict__ active_list,
                                                     const uint32_t *__restrict__ totals, uint32_t capacity,
-                                                    float *__restrict__ out, int group_log2)
+                                                    float *__restrict__ out, int group_log2, int ablate, unsigned *__restrict__ queue, int sub_log2)
 {
     __shared__ EmitLds2 s_lds[kWavesPerWg];
     __shared__ u64 s_vert[256];
@@ -357,8 +375,12 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
     // each XCD (blockIdx % 8 under round-robin dispatch; a speed heuristic only) sweeps one
     // contiguous eighth of the active list
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;  // gridDim % 8 == 0
-    const int ai_begin = (int)((long long)n_active * xcd / 8);
-    const int ai_end = (int)((long long)n_active * (xcd + 1) / 8);
+    // dynamic mode splits every XCD's eighth into n_sub sub-ranges, one ticket counter each (on its
+    // own 256-byte line: counters sharing a line serialise at ~88 atomics/us chip-wide)
+    const int n_sub = queue ? (1 << sub_log2) : 1;
+    const int part = xcd * n_sub + (queue ? (j & (n_sub - 1)) : 0), n_part = 8 * n_sub;
+    const int ai_begin = (int)((long long)n_active * part / n_part);
+    const int ai_end = (int)((long long)n_active * (part + 1) / n_part);
     // the k-th block of this wave: rounds of (waves per XCD) groups, each wave takes 2^group_log2
     // consecutive list entries per round (x-adjacent blocks share 128-byte lines)
     const int u = j * kWavesPerWg + wave, n_u = per_xcd * kWavesPerWg;
@@ -367,17 +389,34 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
         return ai_begin + (((r * n_u + u) << group_log2) | g);
     };
 
+    // Work distribution.  Static: entry(k).  Dynamic (queue != nullptr): one ticket counter per XCD,
+    // so the blocks in flight on an XCD are always the next ones in list order -- spatial neighbours
+    // (shared halo rows / 128-byte lines) stay within the few microseconds a line survives in L2.
+    // The ticket for block k+2 is requested while block k is processed, its tile one block ahead.
+    int k_static = 0;
+    unsigned tick_raw = 0;  // lane 0 holds the ticket the last request returned
+    auto request = [&]() {
+        if (queue) {
+            if (lane == 0) tick_raw = __hip_atomic_fetch_add(queue + part * 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            tick_raw = (unsigned)(entry(k_static++) - ai_begin);
+        }
+    };
+    auto collect = [&]() { return ai_begin + (int)__builtin_amdgcn_readfirstlane(tick_raw); };
+
     float pre[16];
     int b_next = 0;
-    int k = 0;
-    int ai = entry(0);
+    request();
+    int ai = collect();
+    request();
+    int ai_next = collect();
     if (ai < ai_end) {
         b_next = active_list[ai];
         const char *src = reinterpret_cast<const char *>(sp.base + block_origin(sp, b_next));
 #pragma unroll
         for (int it = 0; it < 16; ++it) pre[it] = *reinterpret_cast<const float *>(src + toff[it]);
     }
-    for (; ai < ai_end; ai = entry(++k)) {
+    for (int k = 0; ai < ai_end; ++k) {
         const int b = b_next;
         size_t tri_base = offsets[b];
         // the scan's budget for this block; flushes are clamped to it so a classify/emit mismatch
@@ -386,13 +425,13 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
         VTMC_WAVE_SYNC();
 #pragma unroll
         for (int it = 0; it < 16; ++it) L->tile[tdst[it]] = pre[it];
-        const int ai_next = entry(k + 1);
         if (ai_next < ai_end) {  // prefetch the next block's tile; it lands while this one is processed
-            b_next = active_list[ai_next];
+            b_next = active_list[(ablate & 2) ? ai_begin + (k & 3) : ai_next];
             const char *src = reinterpret_cast<const char *>(sp.base + block_origin(sp, b_next));
 #pragma unroll
             for (int it = 0; it < 16; ++it) pre[it] = *reinterpret_cast<const float *>(src + toff[it]);
         }
+        request();  // ticket for the block after next; collected at the bottom of this iteration
         VTMC_WAVE_SYNC();
 
         // pass 1: cases (CollectTriNum.compute:48-51) + compaction of the cells that hold triangles
@@ -417,7 +456,7 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
         for (int c0 = 0; c0 < n_act; c0 += 64) {
             if (pending > kSlotCap - 320) {  // wave-uniform
                 const int n_out = pending < budget ? pending : budget;
-                emit_flush2<FAST>(L, s_vert, s_edge, n_out, tri_base, b, out, lane);
+                emit_flush2<FAST>(L, s_vert, s_edge, n_out, tri_base, b, out, lane, ablate);
                 tri_base += n_out;
                 budget -= n_out;
                 pending = 0;
@@ -435,13 +474,15 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
             pending += (int)step_total;
         }
         if (pending > budget) pending = budget;
-        if (pending > 0) emit_flush2<FAST>(L, s_vert, s_edge, pending, tri_base, b, out, lane);
+        if (pending > 0) emit_flush2<FAST>(L, s_vert, s_edge, pending, tri_base, b, out, lane, ablate);
+        ai = ai_next;
+        ai_next = collect();
     }
 }
 
 hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets,
                        const int32_t *active_list, const uint32_t *totals, uint32_t capacity,
-                       void *triangles, int n_cus, const Tuning &tune, hipStream_t stream)
+                       void *triangles, int n_cus, const Tuning &tune, unsigned *queue, hipStream_t stream)
 {
     int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : 3;  // LDS-limited residency: 3 x 48 KB
     int wgs = n_cus * per_cu;
@@ -455,9 +496,9 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
             hipLaunchKernelGGL((emit_v1_kernel<1, false, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o);
     } else {
         if (tune.emit_fast_math)
-            hipLaunchKernelGGL((emit_kernel<true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2);
+            hipLaunchKernelGGL((emit_kernel<true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, tune.emit_dynamic ? queue : nullptr, tune.emit_sub_log2);
         else
-            hipLaunchKernelGGL((emit_kernel<false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2);
+            hipLaunchKernelGGL((emit_kernel<false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, tune.emit_dynamic ? queue : nullptr, tune.emit_sub_log2);
     }
     return hipGetLastError();
 }

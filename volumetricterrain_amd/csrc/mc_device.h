@@ -43,12 +43,12 @@ __device__ __forceinline__ long long block_origin(const BlockSpace &s, int b)
         const int *p = s.list + 3ll * b;
         return 8ll * (p[0] * s.sx + p[1] * s.sy + p[2] * s.sz);
     }
-    int v = b / s.bpv;
-    int r = b - v * s.bpv;
-    int q = r / s.nbx;
-    int bx = r - q * s.nbx;
-    int bz = q / s.nby;
-    int by = q - bz * s.nby;
+    const int v = (int)s.d_bpv.quot((unsigned)b);
+    const int r = b - v * s.bpv;
+    const int q = (int)s.d_nbx.quot((unsigned)r);
+    const int bx = r - q * s.nbx;
+    const int bz = (int)s.d_nby.quot((unsigned)q);
+    const int by = q - bz * s.nby;
     return v * s.sv + 8ll * (bx * s.sx + by * s.sy + bz * s.sz);
 }
 

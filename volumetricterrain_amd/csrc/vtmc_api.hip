@@ -126,7 +126,7 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
     if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
     if (int rc = ensure(ctx, ctx->active, sizeof(int32_t) * (size_t)B)) return rc;
     if (int rc = ensure(ctx, ctx->partials, sizeof(uint32_t) * 2 * (size_t)n_tiles)) return rc;
-    if (int rc = ensure(ctx, ctx->totals, sizeof(uint32_t) * 2)) return rc;
+    if (int rc = ensure(ctx, ctx->totals, sizeof(uint32_t) * (64 + kQueueWords))) return rc;  // {T, nActive}, then the emit kernel's ticket counters
     if (int rc = ensure(ctx, ctx->volcounts, sizeof(uint32_t) * 2 * (size_t)std::max(n_volumes, 1))) return rc;
     uint8_t *d_cases = nullptr;
     if (flags & VTMC_FLAG_WANT_CASES) {
@@ -149,8 +149,10 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
 
     for (int attempt = 0; attempt < 2; ++attempt) {
         const size_t cap = std::min<size_t>(ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
+        uint32_t *queue = (uint32_t *)ctx->totals.p + 64;
+        VTMC_HIP(ctx, hipMemsetAsync(queue, 0, kQueueWords * sizeof(uint32_t), stream));
         VTMC_HIP(ctx, launch_emit(sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const int32_t *)ctx->active.p,
-                                  (const uint32_t *)ctx->totals.p, (uint32_t)cap, ctx->tris.p, ctx->n_cus, ctx->tune, stream));
+                                  (const uint32_t *)ctx->totals.p, (uint32_t)cap, ctx->tris.p, ctx->n_cus, ctx->tune, queue, stream));
         VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
         VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->totals.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         VTMC_HIP(ctx, hipStreamSynchronize(stream));
@@ -217,6 +219,9 @@ BlockSpace dense_space(const float *d_base, int nx, int ny, int nz, int64_t sx, 
     sp.list = nullptr;
     sp.zfast = (sz == 1 && sx != 1) ? 1 : 0;
     sp.nx = nx;
+    sp.d_bpv = FastDiv((unsigned)std::max(sp.bpv, 1));
+    sp.d_nbx = FastDiv((unsigned)std::max(sp.nbx, 1));
+    sp.d_nby = FastDiv((unsigned)std::max(sp.nby, 1));
     return sp;
 }
 
@@ -506,6 +511,9 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     const std::string k(key);
     if (k == "emit_version") ctx->tune.emit_version = value;
     else if (k == "emit_fast_math") ctx->tune.emit_fast_math = value;
+    else if (k == "emit_sub_log2") ctx->tune.emit_sub_log2 = value < 0 ? 0 : (value > 4 ? 4 : value);
+    else if (k == "emit_dynamic") ctx->tune.emit_dynamic = value;
+    else if (k == "emit_ablate") ctx->tune.emit_ablate = value;
     else if (k == "emit_group_log2") ctx->tune.emit_group_log2 = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (k == "emit_wgs_per_cu") ctx->tune.emit_wgs_per_cu = value;
     else return fail(ctx, VTMC_ERR_INVALID_ARG, "unknown tuning key '%s'", key);

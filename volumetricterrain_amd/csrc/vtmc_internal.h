@@ -7,6 +7,29 @@
 
 namespace vtmc {
 
+// Division by a launch-constant via multiply-high + shifts (Granlund-Montgomery, exact for every
+// 32-bit numerator): block ids are decomposed per block on the device, a hardware-less integer
+// divide would cost ~40 VALU instructions each.
+struct FastDiv {
+    unsigned mul = 1, sh1 = 0, sh2 = 0, div = 1;
+    FastDiv() = default;
+    explicit FastDiv(unsigned d) : div(d)
+    {
+        unsigned l = 0;
+        while ((1ull << l) < d) ++l;
+        mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+        sh1 = l < 1 ? l : 1;
+        sh2 = l > 0 ? l - 1 : 0;
+    }
+#ifdef __HIPCC__
+    __device__ __forceinline__ unsigned quot(unsigned n) const
+    {
+        unsigned t = __umulhi(mul, n);
+        return (t + ((n - t) >> sh1)) >> sh2;
+    }
+#endif
+};
+
 // How kernels find the 10x10x10 sample tile of block b.
 //  dense: b = v*bpv + bx + nbx*(by + nby*bz)  -> origin = v*sv + 8*(bx*sx + by*sy + bz*sz)
 //  list : (bx,by,bz) = list[3b..3b+2] (the dirty list, VoxelTerrain.cs:321), single volume
@@ -19,6 +42,7 @@ struct BlockSpace {
     const int *list;           // device, n_blocks x 3, or nullptr
     int zfast;                 // sz == 1: tile loads walk z fastest (C# float[,,] layout)
     int nx;                    // cells along x per volume (dense classify)
+    FastDiv d_bpv, d_nbx, d_nby;
 };
 
 struct DeviceTables {
@@ -31,10 +55,14 @@ struct Tuning {
     int emit_version = 2;     // 1: first-round kernel (kept for A/B), 2: prefetching / compacting kernel
     int emit_fast_math = 1;   // 1: v_rcp/v_rsq (<= ~5e-7 from exact); 0: correctly rounded, bit-compatible with the oracle
     int emit_wgs_per_cu = 3;
+    int emit_sub_log2 = 1;    // dynamic mode: 2^s ticket counters per XCD
+    int emit_dynamic = 1;     // per-XCD ticket counters instead of a static round-robin over the active list
+    int emit_ablate = 0;      // diagnostics only: 1 skip stores, 2 re-read hot tiles, 4 skip vertex math (output invalid)
     int emit_group_log2 = 0;  // each wave takes 2^g consecutive active-list entries per round
 };
 
 // scan scratch layout
+constexpr int kQueueWords = 8 * 16 * 64;  // up to 16 ticket counters per XCD, 256 bytes apart
 constexpr int kScanTile = 2048;  // block counts per scan workgroup (256 threads x 8)
 
 // Launch wrappers (mc_kernels.hip).  All asynchronous on `stream`; return hipGetLastError().
@@ -47,7 +75,7 @@ hipError_t launch_scan(const uint32_t *counts, int n_blocks, uint32_t *offsets, 
                        uint32_t *volume_counts, hipStream_t stream);
 hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets,
                        const int32_t *active_list, const uint32_t *totals, uint32_t capacity,
-                       void *triangles, int n_cus, const Tuning &tune, hipStream_t stream);
+                       void *triangles, int n_cus, const Tuning &tune, unsigned *queue, hipStream_t stream);
 
 // density.hip
 struct DensityLaunch {
