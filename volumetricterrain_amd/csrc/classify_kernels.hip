@@ -328,8 +328,8 @@ hipError_t launch_classify_blocks(const BlockSpace &sp, const DeviceTables &tb, 
 hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
                                  hipStream_t stream)
 {
-    int nsegx = (sp.nx + 63) / 64;
-    long long n_vol = sp.n_blocks / sp.bpv;
+    const int nsegx = (sp.nx + 63) / 64;
+    const long long n_vol = sp.n_blocks / sp.bpv;
     long long n_bricks = n_vol * sp.nbz * sp.nby * nsegx;
     long long n_wgs = (n_bricks + kWavesPerWg - 1) / kWavesPerWg;
     if (n_wgs > 0x7fffffffll) return hipErrorInvalidValue;
