@@ -4,7 +4,7 @@
 Workload (BASELINE.json configs[2], the one `metric` is quoted on): a 1024^3-cell perlin3d grid
 held as 8^3 chunks of 128^3 cells (130^3 samples each, 4.50 GB), resident in HBM.  One "step" =
 one pass of the hot path over that batch: classify+count -> prefix scan / compaction -> fused
-normals + triangle emit, ending when the host knows T (and, for N > 1, after the RCCL all-gather
+normals + triangle emit (--sweep: the experimental single-pass kernel), ending when the host knows T (and, for N > 1, after the RCCL all-gather
 of the per-chunk {vertex, triangle} counts).  Weak scaling: every rank owns 512 chunks of a
 1024 x 1024 x (1024*N) world, chunk c -> rank c % N.
 
@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chunks", type=int, default=8, help="chunks the CPU oracle is timed on")
     ap.add_argument("--no-dense", action="store_true", help="A/B: force the per-block classify kernel")
+    ap.add_argument("--sweep", action="store_true", help="A/B: the experimental single-pass kernel instead of classify -> scan -> emit")
     return ap.parse_args()
 
 
@@ -133,6 +134,9 @@ def main():
     sampler_s = time.perf_counter() - t0
 
     flags = 2 if args.no_dense else 0
+    if args.sweep:
+        ex.set_tuning(sweep=1)
+    fused = args.sweep and not args.no_dense
     counts_dev = torch.zeros((n_chunks, 2), dtype=torch.int32, device="cuda")
     stage_acc = {"classify": 0.0, "scan": 0.0, "emit": 0.0, "total": 0.0}
 
@@ -195,7 +199,11 @@ def main():
             "emit": 76.0 * T + 4000.0 * n_active,
             "scan": 4.0 * n_chunks * bpv * 3,
         }
-        dom = max(("classify", "emit"), key=lambda k: avg[k])
+        if fused:
+            # single-pass kernel: every sample read once, one offset per block and every triangle written once
+            alg["sweep"] = 4.0 * samples + 4.0 * n_chunks * bpv + 76.0 * T
+            avg["sweep"] = avg["classify"]
+        dom = "sweep" if fused else max(("classify", "emit"), key=lambda k: avg[k])
         ach = alg[dom] / (avg[dom] * 1e-3) / 1e9
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -208,7 +216,7 @@ def main():
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes": alg[dom], "avg_ms": round(avg[dom], 4)}
         per_kernel = {k: {"avg_ms": round(avg[k], 4), "alg_GBps": round(alg[k] / (avg[k] * 1e-3) / 1e9, 1) if avg[k] > 0 else None}
-                      for k in ("classify", "scan", "emit")}
+                      for k in (("sweep",) if fused else ("classify", "scan", "emit"))}
         # SURVEY.md 8d whole-path figure on one rank: 4*S + 76*T + 8*C over the device time of the three stages
         path_bytes = 4.0 * samples + 76.0 * T + 8.0 * n_chunks
         path = {"bytes": path_bytes, "device_ms": round(avg["total"], 4),
@@ -234,7 +242,7 @@ def main():
             "config": {"workload": "%s %d^3 cells per GPU as %d chunks of %d^3 (130^3 samples incl. halo), chunk c -> rank c %% N"
                                    % (args.kind, n, n_chunks, c),
                        "grid": n, "chunk": c, "chunks_per_gpu": n_chunks, "kind": args.kind, "seed": 1337,
-                       "classify_kernel": "per-block" if args.no_dense else "dense"},
+                       "pipeline": "single-pass sweep kernel" if fused else ("classify(per-block) -> scan -> emit" if args.no_dense else "classify(dense) -> scan -> emit")},
             "mtris_per_s": round(total_tris / (elapsed / args.steps) / 1e6, 1),
             "triangles_per_gpu": int(T),
             "active_blocks_per_gpu": n_active,

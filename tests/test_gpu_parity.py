@@ -11,6 +11,7 @@ import fields
 pytestmark = pytest.mark.gpu
 
 ATOL = 1e-5  # north_star tolerance for positions / normals
+SWEEP_DEFAULT = 0  # shipped pipeline: classify -> scan -> emit (sweep=1: the single-pass kernel)
 
 
 @pytest.fixture(scope="module")
@@ -40,22 +41,19 @@ def assert_tris_match(got, want, atol=ATOL):
 
 def test_exact_mode_is_bit_compatible_with_oracle(ex, oracle_mod):
     """emit_fast_math=0: correctly rounded divide / sqrt, contraction off => identical floats
-    (up to the sign of zero); both emit kernel generations.  The shipped default (v_rcp / v_rsq)
-    stays within ATOL and is what every other test runs."""
+    (up to the sign of zero), in both pipelines.  The shipped default (v_rcp / v_rsq / fma) stays
+    within ATOL and is what every other test runs."""
     g = oracle_mod.density_volume("perlin3d", 64)
     want, want_offs, _ = oracle_mod.extract_grid(g, threads=8)
     try:
-        for version in (2, 1):
-            ex.set_tuning(emit_fast_math=0, emit_version=version)
+        for sweep in (0, 1):
+            ex.set_tuning(emit_fast_math=0, sweep=sweep)
             assert ex.extract_grid(g) == len(want)
             got, offs = ex.read_triangles()
             assert np.array_equal(offs, want_offs)
             assert assert_tris_match(got, want, atol=0.0) == 0.0
-        ex.set_tuning(emit_fast_math=1, emit_version=1)
-        assert ex.extract_grid(g) == len(want)
-        assert_tris_match(ex.read_triangles(False), want)
     finally:
-        ex.set_tuning(emit_fast_math=1, emit_version=2)
+        ex.set_tuning(emit_fast_math=1, sweep=SWEEP_DEFAULT)
     assert ex.extract_grid(g) == len(want)
     worst = assert_tris_match(ex.read_triangles(False), want)
     assert worst <= 2e-6, worst     # fast path: observed ~5e-7, bar 1e-5
@@ -64,7 +62,7 @@ def test_exact_mode_is_bit_compatible_with_oracle(ex, oracle_mod):
 def test_exact_zero_samples_and_unit_weights(ex, oracle_mod):
     """Samples that are exactly 0 give t = -0 / t = 1 (vertices ON lattice points).  A 1-ulp
     reciprocal must not step floor/ceil past the edge (regression: garbage lattice reads turned a
-    zero-weight normal into NaN).  The v1 kernel runs first so LDS holds foreign leftovers."""
+    zero-weight normal into NaN).  The exact-mode kernel runs first so LDS holds foreign leftovers."""
     rng = np.random.default_rng(11)
     n = (32, 32, 32)
     g = fields.random_field(n, seed=3)
@@ -72,10 +70,11 @@ def test_exact_zero_samples_and_unit_weights(ex, oracle_mod):
     g[...] = np.where(rng.random(g.shape) < 0.5, ints, g)      # half the samples are small integers, many 0
     want, want_offs, _ = oracle_mod.extract_grid(g, threads=8)
     try:
-        ex.set_tuning(emit_version=1, emit_fast_math=0)
-        ex.extract_grid(g)
+        ex.set_tuning(emit_fast_math=0)
+        assert ex.extract_grid(g) == len(want)
+        assert_tris_match(ex.read_triangles(False), want, atol=0.0)
     finally:
-        ex.set_tuning(emit_version=2, emit_fast_math=1)
+        ex.set_tuning(emit_fast_math=1)
     for _ in range(2):
         assert ex.extract_grid(g) == len(want)
         got, offs = ex.read_triangles()
@@ -110,15 +109,38 @@ def test_grid_in_place_matches_oracle(ex, oracle_mod, order):
     assert_tris_match(got, want)
 
 
-def test_non_cubic_and_partial_segments(ex, oracle_mod):
-    """nx = 40 / 72 exercise partial 64-lane segments of the dense classify kernel."""
-    for n in ((40, 16, 24), (72, 8, 16), (136, 8, 8)):
-        g = fields.random_field(n, seed=n[0])
-        want, want_offs, _ = oracle_mod.extract_grid(g, threads=8)
-        assert ex.extract_grid(g) == len(want)
-        got, offs = ex.read_triangles()
-        assert np.array_equal(offs, want_offs)
-        assert_tris_match(got, want)
+@pytest.mark.parametrize("sweep", [1, 0])
+def test_non_cubic_and_partial_segments(ex, oracle_mod, sweep):
+    """nx = 40 / 72 exercise partial 64-lane segments of the streaming classify; sweep=1 is the
+    single-pass kernel (default), sweep=0 the classify -> scan -> emit kernels."""
+    try:
+        ex.set_tuning(sweep=sweep)
+        for n in ((40, 16, 24), (72, 8, 16), (136, 8, 8), (32, 8, 8), (200, 24, 8)):
+            g = fields.random_field(n, seed=n[0])
+            want, want_offs, _ = oracle_mod.extract_grid(g, threads=8)
+            assert ex.extract_grid(g) == len(want)
+            got, offs = ex.read_triangles()
+            assert np.array_equal(offs, want_offs)
+            assert_tris_match(got, want)
+    finally:
+        ex.set_tuning(sweep=SWEEP_DEFAULT)
+
+
+def test_sweep_and_staged_pipelines_agree_bitwise(ex, oracle_mod):
+    """The single-pass kernel and the three-stage pipeline share the emit routine: same bytes out.
+    A buffer that is too small on the first call (reserve 1) exercises the count-then-regrow path."""
+    g = oracle_mod.density_volume("perlin3d", 128)
+    outs = []
+    try:
+        for sweep in (1, 0):
+            ex.set_tuning(sweep=sweep)
+            ex.reserve_triangles(1)
+            T = ex.extract_grid(g)
+            tris, offs = ex.read_triangles()
+            outs.append((T, tris.tobytes(), offs.tobytes()))
+    finally:
+        ex.set_tuning(sweep=SWEEP_DEFAULT)
+    assert outs[0] == outs[1]
 
 
 def test_dirty_block_list(ex, oracle_mod):

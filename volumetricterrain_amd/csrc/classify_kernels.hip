@@ -59,18 +59,9 @@ __global__ __launch_bounds__(256) void classify_blocks_kernel(BlockSpace sp, Dev
 // reduced over 8-lane groups.  Each sample is requested once per brick (9/8 x 9/8 halo re-reads
 // are served by L2).  No per-cell output: cases are recomputed by the emit kernel from its LDS tile.
 // ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned extract9(u64 e0, u64 e1, int r0)
-{
-    u64 v;
-    if (r0 + 9 <= 64) v = e0 >> r0;
-    else if (r0 >= 64) v = e1 >> (r0 - 64);
-    else v = (e0 >> r0) | (e1 << (64 - r0));
-    return (unsigned)v & 0x1FFu;
-}
-
 __global__ __launch_bounds__(256) void classify_dense_kernel(BlockSpace sp, DeviceTables tb,
                                                               uint32_t *__restrict__ counts,
-                                                              int nsegx, int n_bricks, int n_wgs)
+                                                              int nsegx, int n_bricks, int n_wgs, int ablate)
 {
     __shared__ unsigned char s_trinum[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -100,73 +91,7 @@ __global__ __launch_bounds__(256) void classify_dense_kernel(BlockSpace sp, Devi
     xe = xe < sp.nx + 1 ? xe : sp.nx + 1;
     const float *brick_base = sp.base + v * sp.sv + (8ll * by) * sp.sy + (8ll * bz) * sp.sz;
 
-    // 81 row loads, lane-contiguous
-    float val[9][9];
-#pragma unroll
-    for (int zz = 0; zz < 9; ++zz)
-#pragma unroll
-        for (int yy = 0; yy < 9; ++yy) val[zz][yy] = brick_base[gxc + yy * sp.sy + zz * sp.sz];
-    // 65th column: row r = zz*9 + yy is read by lane r (two passes cover 81 rows)
-    float ex0, ex1;
-    {
-        int r = lane, zz = r / 9, yy = r - 9 * zz;
-        ex0 = brick_base[xe + yy * sp.sy + zz * sp.sz];
-        r = lane + 64;
-        r = r < 81 ? r : 80;
-        zz = r / 9;
-        yy = r - 9 * zz;
-        ex1 = brick_base[xe + yy * sp.sy + zz * sp.sz];
-    }
-
-    unsigned A[9], N[9];
-#pragma unroll
-    for (int zz = 0; zz < 9; ++zz) {
-        unsigned a = 0;
-#pragma unroll
-        for (int yy = 0; yy < 9; ++yy) a |= (unsigned)(val[zz][yy] > 0.f) << yy;
-        A[zz] = a;
-    }
-    const u64 e0 = __builtin_amdgcn_ballot_w64(ex0 > 0.f);
-    const u64 e1 = __builtin_amdgcn_ballot_w64(ex1 > 0.f);
-    unsigned or_all = 0, and_all = 0x1FFu;
-#pragma unroll
-    for (int zz = 0; zz < 9; ++zz) {
-        unsigned nb = (unsigned)__shfl_down((int)A[zz], 1);
-        unsigned ne = extract9(e0, e1, zz * 9);
-        N[zz] = lane == 63 ? ne : nb;
-        or_all |= A[zz] | N[zz];
-        and_all &= A[zz] & N[zz];
-    }
-
-    unsigned total = 0;
-    const bool uniform = (or_all == 0u) || (and_all == 0x1FFu);
-    if (__builtin_amdgcn_ballot_w64(!uniform) != 0) {
-        // NIB[zz] nibble yy = corners (0,1,2,3) of the cell column at sample layer zz
-        unsigned NIB[9];
-#pragma unroll
-        for (int zz = 0; zz < 9; ++zz) {
-            unsigned w = 0;
-#pragma unroll
-            for (int yy = 0; yy < 8; ++yy) {
-                unsigned a2 = (A[zz] >> yy) & 3u, n2 = (N[zz] >> yy) & 3u;
-                unsigned nib = (a2 & 1u) | (n2 << 1) | ((a2 & 2u) << 2);
-                w |= nib << (4 * yy);
-            }
-            NIB[zz] = w;
-        }
-#pragma unroll
-        for (int zz = 0; zz < 8; ++zz) {
-            const unsigned lo = NIB[zz], hi = NIB[zz + 1];
-            const bool flat = ((lo | hi) == 0u) || ((lo & hi) == 0xFFFFFFFFu);
-            if (__builtin_amdgcn_ballot_w64(!flat) == 0) continue;
-#pragma unroll
-            for (int yy = 0; yy < 8; ++yy) {
-                unsigned cs = ((lo >> (4 * yy)) & 15u) | (((hi >> (4 * yy)) & 15u) << 4);
-                total += s_trinum[cs];
-            }
-        }
-        if (gx >= sp.nx) total = 0;  // lanes past the last cell of a partial segment
-    }
+    unsigned total = classify_brick_column(sp, s_trinum, brick_base, gx, gxc, xe, lane, ablate);
     // 8-lane group sums = per-block counts
     total += __shfl_xor(total, 1);
     total += __shfl_xor(total, 2);
@@ -326,7 +251,7 @@ hipError_t launch_classify_blocks(const BlockSpace &sp, const DeviceTables &tb, 
 }
 
 hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
-                                 hipStream_t stream)
+                                 int ablate, hipStream_t stream)
 {
     const int nsegx = (sp.nx + 63) / 64;
     const long long n_vol = sp.n_blocks / sp.bpv;
@@ -334,7 +259,7 @@ hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, u
     long long n_wgs = (n_bricks + kWavesPerWg - 1) / kWavesPerWg;
     if (n_wgs > 0x7fffffffll) return hipErrorInvalidValue;
     hipLaunchKernelGGL(classify_dense_kernel, dim3((unsigned)n_wgs), dim3(256), 0, stream, sp, tb, counts, nsegx,
-                       (int)n_bricks, (int)n_wgs);
+                       (int)n_bricks, (int)n_wgs, ablate);
     return hipGetLastError();
 }
 

@@ -1,0 +1,240 @@
+// emit_device.h -- device code shared by the kernels that emit triangles (emit_kernels.hip: one wave
+// per non-empty block after the scan; sweep_kernels.hip: the single-pass kernel): lattice normals
+// (Shaders/SampleNormal.compute:27-33), edge vertices and the trilinear normal fetch
+// (Shaders/MarchingCube.compute:69-99, 128-133), triangle records (MarchingCube.compute:143-162).
+#ifndef VTMC_EMIT_DEVICE_H
+#define VTMC_EMIT_DEVICE_H
+#include "mc_device.h"
+
+namespace vtmc {
+
+constexpr int kTriDwords = 19;     // 76-byte record
+
+// ----------------------------------------------------------------------------------------------
+// Per-block emit, shared by emit_kernel and sweep_kernel:
+//   * pass 1 classifies (8 unrolled layers) and compacts the ACTIVE cells with one ballot per layer;
+//   * pass 2 runs the triangle-slot prefix sum over 64 active cells at a time; a slot carries the
+//     cell and the triangle's three edge ids, read from the packed table once per CELL;
+//   * the flush gives one lane per triangle: all LDS reads of its three vertices are issued before
+//     any staging write (three independent chains in flight instead of one), edge geometry comes
+//     from a 60-bit constant, a vertex is computed along its edge axis only (one lerp, one
+//     floor/ceil); FAST uses v_rcp / v_rsq / fma (results within ~5e-7 of the exact path; the
+//     north-star bar is 1e-5), !FAST is bit-compatible with the CPU oracle.
+// ----------------------------------------------------------------------------------------------
+constexpr int kSlotCap = 384;  // triangle slots kept before a flush (a step adds at most 320)
+
+struct __attribute__((aligned(16))) EmitLds2 {
+    float tile[1000];
+    unsigned slot[kSlotCap];        // triangle slot -> cell | edge triple << 9
+    unsigned short acell[512];      // active cells of the block, ascending cell id
+    unsigned char cases[512];
+    float stage[64 * kTriDwords + 4];
+};
+static_assert(sizeof(EmitLds2) % 16 == 0 && offsetof(EmitLds2, stage) % 16 == 0, "stage must stay 16-byte aligned");
+
+// Edge geometry, 5 bits per edge: offset of endpoint a (x | y << 1 | z << 2) | axis << 3
+// (corner offsets MarchingCube.compute:46-50, edge endpoints MarchingCube.compute:40-43).
+__host__ __device__ constexpr u64 edge_geom_word()
+{
+    const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3};
+    const int eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+    u64 w = 0;
+    for (int e = 0; e < 12; ++e) {
+        const int a = ea[e], b = eb[e];
+        const int oax = (0x66 >> a) & 1, oay = (0xCC >> a) & 1, oaz = (0xF0 >> a) & 1;
+        const int obx = (0x66 >> b) & 1, oby = (0xCC >> b) & 1;
+        const int axis = oax != obx ? 0 : (oay != oby ? 1 : 2);
+        w |= (u64)(oax | (oay << 1) | (oaz << 2) | (axis << 3)) << (5 * e);
+    }
+    return w;
+}
+constexpr u64 kEdgeGeom = edge_geom_word();
+
+// Where a vertex on cube edge e of cell (cx,cy,cz) lives: tile indices of the edge's endpoints a, b
+// (in the reference's order), the edge axis and endpoint a's integer coordinates.
+struct EdgeSite {
+    int ta, tb, sk, iak;
+    unsigned axis, back;
+    int ia[3];
+};
+
+__device__ __forceinline__ EdgeSite edge_site(int cx, int cy, int cz, int tcell, unsigned e)
+{
+    EdgeSite s;
+    const unsigned g = (unsigned)(kEdgeGeom >> (5u * e)) & 31u;
+    const unsigned oax = g & 1u, oay = (g >> 1) & 1u, oaz = (g >> 2) & 1u;
+    s.axis = g >> 3;
+    s.sk = s.axis == 0 ? 1 : (s.axis == 1 ? 10 : 100);
+    s.back = s.axis == 0 ? oax : (s.axis == 1 ? oay : oaz);  // a sits on the far end: the edge runs towards -axis
+    s.ta = tcell + (int)oax + 10 * (int)oay + 100 * (int)oaz;
+    s.tb = s.back ? s.ta - s.sk : s.ta + s.sk;
+    s.ia[0] = cx + (int)oax;
+    s.ia[1] = cy + (int)oay;
+    s.ia[2] = cz + (int)oaz;
+    s.iak = s.axis == 0 ? s.ia[0] : (s.axis == 1 ? s.ia[1] : s.ia[2]);
+    return s;
+}
+
+// gradient of SampleNormal.compute:27-30 at tile index ti, not yet normalised
+__device__ __forceinline__ void lattice_gradient(const float *tile, int ti, float d[3])
+{
+    const float v = tile[ti];
+    d[0] = v - tile[ti + 1];
+    d[1] = v - tile[ti + 10];
+    d[2] = v - tile[ti + 100];
+}
+
+template <bool FAST>
+__device__ __forceinline__ void normalise(float d[3])
+{
+    if (FAST) {
+        const float len2 = __builtin_fmaf(d[2], d[2], __builtin_fmaf(d[1], d[1], d[0] * d[0]));
+        const float r = __builtin_amdgcn_rsqf(len2);
+        d[0] *= r;
+        d[1] *= r;
+        d[2] *= r;
+    } else {
+        const float len2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        const float len = __builtin_sqrtf(len2);  // correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt)
+        d[0] /= len;
+        d[1] /= len;
+        d[2] /= len;
+    }
+}
+
+// One lane per triangle.  Vertex = position along the edge (MarchingCube.compute:128-133: t =
+// -cube[a] / (cube[b] - cube[a]), lerp with v-u = +-1 on the edge axis and 0 on the others) and the
+// trilinear normal fetch of MarchingCube.compute:69-99, which on a lattice edge is a 2-point lerp
+// whose weight comes from the ROUNDED position (c0 = floor(P), c1 = ceil(P), t = P - c0).
+template <bool FAST>
+__device__ __forceinline__ void emit_flush2(EmitLds2 *L, int pending, size_t tri_base, int block_id,
+                                            float *__restrict__ out, int lane, int ablate)
+{
+    VTMC_WAVE_SYNC();
+    for (int s0 = 0; s0 < pending; s0 += 64) {
+        const int s = s0 + lane;
+        const size_t d0 = (tri_base + (size_t)s0) * kTriDwords;  // first global dword of this batch
+        const int sh = (int)(d0 & 3);                            // staging shift = global misalignment
+        if (s < pending && !(ablate & 4)) {
+            const unsigned sc = L->slot[s];
+            const int cell = sc & 511u;
+            const unsigned trip = sc >> 9;
+            const int cx = cell & 7, cy = (cell >> 3) & 7, cz = cell >> 6;
+            const int tcell = cx + 10 * cy + 100 * cz;
+            // table entries (3i, 3i+2, 3i+1): the winding swap of MarchingCube.compute:147-157
+            const unsigned e[3] = {trip & 15u, (trip >> 8) & 15u, (trip >> 4) & 15u};
+            const float *tile = L->tile;
+            EdgeSite es[3];
+            float va[3], vb[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                es[k] = edge_site(cx, cy, cz, tcell, e[k]);
+                va[k] = tile[es[k].ta];
+                vb[k] = tile[es[k].tb];
+            }
+            float q[3], w[3], g0[3][3], g1[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                // t lies in [0,1] (the endpoints differ in sign class); the 1-ulp v_rcp can land a hair
+                // outside, which would push floor/ceil one lattice point beyond the edge -- clamp it back
+                const float t = FAST ? __builtin_amdgcn_fmed3f(-va[k] * __builtin_amdgcn_rcpf(vb[k] - va[k]), 0.0f, 1.0f)
+                                     : (-va[k]) / (vb[k] - va[k]);
+                q[k] = (float)es[k].iak + (es[k].back ? -t : t);
+                const float fq = floorf(q[k]);
+                w[k] = q[k] - fq;
+                const int l0 = es[k].ta + ((int)fq - es[k].iak) * es[k].sk;
+                const int l1 = es[k].ta + ((int)ceilf(q[k]) - es[k].iak) * es[k].sk;
+                lattice_gradient(tile, l0, g0[k]);
+                lattice_gradient(tile, l1, g1[k]);
+            }
+            float *rec = L->stage + sh + lane * kTriDwords;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                normalise<FAST>(g0[k]);
+                normalise<FAST>(g1[k]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    rec[3 * k + c] = es[k].axis == (unsigned)c ? q[k] : (float)es[k].ia[c];
+                    rec[9 + 3 * k + c] = FAST ? __builtin_fmaf(w[k], g1[k][c] - g0[k][c], g0[k][c])
+                                              : g0[k][c] + w[k] * (g1[k][c] - g0[k][c]);
+                }
+            }
+            rec[18] = __int_as_float(block_id);
+        }
+        VTMC_WAVE_SYNC();
+        const int cnt = pending - s0 < 64 ? pending - s0 : 64;
+        const int lo = sh, hi = sh + cnt * kTriDwords;
+        float *gal = out + (d0 - sh);  // 16-byte aligned
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        // body: whole 16-byte quads, no per-element predicates (write-once stream: non-temporal)
+        const int body_lo = (lo + 3) & ~3, body_hi = hi & ~3;
+        if (!(ablate & 1)) {
+            for (int q4 = body_lo + 4 * lane; q4 < body_hi; q4 += 256)
+                __builtin_nontemporal_store(*reinterpret_cast<const v4f *>(L->stage + q4), reinterpret_cast<v4f *>(gal + q4));
+        }
+        // head (< 4 dwords before the first whole quad) and tail (< 4 after the last): lanes 0-3 / 4-7
+        {
+            const int k = lane & 3;
+            const int idx = lane < 4 ? lo + k : body_hi + k;
+            const bool on = lane < 4 ? (idx < body_lo && idx < hi) : (lane < 8 && idx < hi && idx >= body_lo);
+            if (on) __builtin_nontemporal_store(L->stage[idx], gal + idx);
+        }
+        VTMC_WAVE_SYNC();
+    }
+}
+
+// Passes 1 + 2 + flush of one block whose 10^3 tile is already in L->tile: cases
+// (CollectTriNum.compute:48-51), compaction of the cells that hold triangles, triangle slots, then
+// one lane per triangle.  `budget` = the scan's triangle count of the block; flushes are clamped to
+// it so a classify/emit mismatch could never write outside the block's own slice of the buffer.
+template <bool FAST>
+__device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_vert, size_t tri_base, int budget,
+                                                     int block_id, float *__restrict__ out, int lane, int ablate)
+{
+    const int t0 = (lane & 7) + 10 * (lane >> 3);
+    // pass 1
+    int n_act = 0;
+    unsigned lo = layer_nibble(L->tile, t0, 0);
+#pragma unroll
+    for (int z = 0; z < 8; ++z) {
+        const unsigned hi = layer_nibble(L->tile, t0, z + 1);
+        const unsigned cs = lo | (hi << 4);
+        lo = hi;
+        const int cell = 64 * z + lane;
+        L->cases[cell] = (unsigned char)cs;
+        const bool act = ((cs + 1u) & 0xFFu) > 1u;  // neither 0x00 nor 0xFF
+        const u64 m = __builtin_amdgcn_ballot_w64(act);
+        if (act) L->acell[n_act + (int)lanes_below(m)] = (unsigned short)cell;
+        n_act += __builtin_popcountll(m);
+    }
+    VTMC_WAVE_SYNC();
+
+    // pass 2: triangle slots, 64 active cells per step
+    int pending = 0;
+    for (int c0 = 0; c0 < n_act; c0 += 64) {
+        if (pending > kSlotCap - 320) {  // wave-uniform
+            const int n_out = pending < budget ? pending : budget;
+            emit_flush2<FAST>(L, n_out, tri_base, block_id, out, lane, ablate);
+            tri_base += n_out;
+            budget -= n_out;
+            pending = 0;
+        }
+        const int idx = c0 + lane;
+        const bool valid = idx < n_act;
+        const unsigned cell = valid ? L->acell[idx] : 0u;
+        const u64 vw = valid ? s_vert[L->cases[cell]] : 0ull;  // fifteen 4-bit edge ids + the count in the top nibble
+        const unsigned n = (unsigned)(vw >> 60);
+        unsigned step_total;
+        const unsigned pre_n = wave_prefix3(n, step_total);
+        unsigned *dst = L->slot + pending + pre_n;
+#pragma unroll
+        for (unsigned i = 0; i < 5; ++i)
+            if (i < n) dst[i] = cell | (((unsigned)(vw >> (12 * i)) & 0xFFFu) << 9);
+        pending += (int)step_total;
+    }
+    if (pending > budget) pending = budget;
+    if (pending > 0) emit_flush2<FAST>(L, pending, tri_base, block_id, out, lane, ablate);
+}
+
+}  // namespace vtmc
+#endif

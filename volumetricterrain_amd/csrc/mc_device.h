@@ -83,5 +83,97 @@ __device__ __forceinline__ unsigned layer_nibble(const float *tile, int t0, int 
            ((unsigned)(p[10] > 0.f) << 3);
 }
 
+__device__ __forceinline__ unsigned extract9(u64 e0, u64 e1, int r0)
+{
+    u64 v;
+    if (r0 + 9 <= 64) v = e0 >> r0;
+    else if (r0 >= 64) v = e1 >> (r0 - 64);
+    else v = (e0 >> r0) | (e1 << (64 - r0));
+    return (unsigned)v & 0x1FFu;
+}
+
+// Streaming classify of one brick of 64 x 8 x 8 cells (8 blocks along x) by one wave, lane = x:
+// 81 coalesced 256-byte row loads + one strided load for the 65th column.  Signs are kept as bit
+// planes, the case of a cell (CollectTriNum.compute:27-51) is assembled from 4 row bit-pairs,
+// triangle counts come from the 256-byte LDS table.  Returns the triangle count of this lane's
+// 8 x 8 cell column; the sum over an 8-lane group is a block's count.
+__device__ __forceinline__ unsigned classify_brick_column(const BlockSpace &sp, const unsigned char *s_trinum,
+                                                          const float *brick_base, int gx, int gxc, int xe, int lane,
+                                                          int ablate = 0)
+{
+    // 81 row loads, lane-contiguous
+    float val[9][9];
+#pragma unroll
+    for (int zz = 0; zz < 9; ++zz)
+#pragma unroll
+        for (int yy = 0; yy < 9; ++yy) {
+            // diagnostics only (ablate & 1): alias the halo rows to their neighbours, i.e. no halo traffic
+            const int y2 = (ablate & 1) && yy == 8 ? 7 : yy, z2 = (ablate & 1) && zz == 8 ? 7 : zz;
+            val[zz][yy] = brick_base[gxc + y2 * sp.sy + z2 * sp.sz];
+        }
+    // 65th column: row r = zz*9 + yy is read by lane r (two passes cover 81 rows)
+    float ex0, ex1;
+    {
+        int r = lane, zz = r / 9, yy = r - 9 * zz;
+        ex0 = brick_base[xe + yy * sp.sy + zz * sp.sz];
+        r = lane + 64;
+        r = r < 81 ? r : 80;
+        zz = r / 9;
+        yy = r - 9 * zz;
+        ex1 = brick_base[xe + yy * sp.sy + zz * sp.sz];
+    }
+
+    unsigned A[9], N[9];
+#pragma unroll
+    for (int zz = 0; zz < 9; ++zz) {
+        unsigned a = 0;
+#pragma unroll
+        for (int yy = 0; yy < 9; ++yy) a |= (unsigned)(val[zz][yy] > 0.f) << yy;
+        A[zz] = a;
+    }
+    const u64 e0 = __builtin_amdgcn_ballot_w64(ex0 > 0.f);
+    const u64 e1 = __builtin_amdgcn_ballot_w64(ex1 > 0.f);
+    unsigned or_all = 0, and_all = 0x1FFu;
+#pragma unroll
+    for (int zz = 0; zz < 9; ++zz) {
+        unsigned nb = (unsigned)__shfl_down((int)A[zz], 1);
+        unsigned ne = extract9(e0, e1, zz * 9);
+        N[zz] = lane == 63 ? ne : nb;
+        or_all |= A[zz] | N[zz];
+        and_all &= A[zz] & N[zz];
+    }
+
+    unsigned total = 0;
+    const bool uniform = (or_all == 0u) || (and_all == 0x1FFu);
+    if (__builtin_amdgcn_ballot_w64(!uniform) != 0) {
+        // NIB[zz] nibble yy = corners (0,1,2,3) of the cell column at sample layer zz
+        unsigned NIB[9];
+#pragma unroll
+        for (int zz = 0; zz < 9; ++zz) {
+            unsigned w = 0;
+#pragma unroll
+            for (int yy = 0; yy < 8; ++yy) {
+                unsigned a2 = (A[zz] >> yy) & 3u, n2 = (N[zz] >> yy) & 3u;
+                unsigned nib = (a2 & 1u) | (n2 << 1) | ((a2 & 2u) << 2);
+                w |= nib << (4 * yy);
+            }
+            NIB[zz] = w;
+        }
+#pragma unroll
+        for (int zz = 0; zz < 8; ++zz) {
+            const unsigned lo = NIB[zz], hi = NIB[zz + 1];
+            const bool flat = ((lo | hi) == 0u) || ((lo & hi) == 0xFFFFFFFFu);
+            if (__builtin_amdgcn_ballot_w64(!flat) == 0) continue;
+#pragma unroll
+            for (int yy = 0; yy < 8; ++yy) {
+                unsigned cs = ((lo >> (4 * yy)) & 15u) | (((hi >> (4 * yy)) & 15u) << 4);
+                total += s_trinum[cs];
+            }
+        }
+        if (gx >= sp.nx) total = 0;  // lanes past the last cell of a partial segment
+    }
+    return total;
+}
+
 }  // namespace vtmc
 #endif

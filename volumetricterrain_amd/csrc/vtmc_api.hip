@@ -41,8 +41,8 @@ struct vtmc_ctx {
     hipStream_t stream = nullptr;
     DeviceTables tables{nullptr, nullptr};
     DevBuf d_vert, d_trinum;
-    DevBuf counts, offsets, active, partials, totals, volcounts, cases, tris, input, list, perm, origins;
-    uint32_t *h_totals = nullptr;  // pinned, 2 x u32
+    DevBuf counts, offsets, active, partials, totals, volcounts, cases, tris, input, list, perm, origins, sweep;
+    uint32_t *h_totals = nullptr;  // pinned: {T, nActive} of the scan, or the sweep kernel's kCtrlWords control words
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float stage_ms[4] = {0, 0, 0, 0};
     // last result
@@ -121,25 +121,57 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
     // the emit kernel addresses a tile with 32-bit byte offsets from the block origin
     if ((9.0 * ((double)sp.sx + (double)sp.sy + (double)sp.sz) + 1.0) * 4.0 >= 4294967296.0)
         return fail(ctx, VTMC_ERR_TOO_LARGE, "strides too large: a 10x10x10 tile must span less than 4 GiB");
+    if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
+    if (int rc = ensure(ctx, ctx->volcounts, sizeof(uint32_t) * 2 * (size_t)std::max(n_volumes, 1))) return rc;
+    if (!ctx->tris.p)
+        if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * ((size_t)1 << 20))) return rc;
+
+    const bool dense = !sp.list && sp.sx == 1 && sp.nx >= 32 && !(flags & (VTMC_FLAG_WANT_CASES | VTMC_FLAG_NO_DENSE_PATH));
+    int64_t T_found = 0;
+
+    if (dense && ctx->tune.sweep) {
+        // single pass: classify + chained scan + emit in one kernel (sweep_kernels.hip).  The kernel
+        // counts every triangle but writes only those below the buffer's capacity, so a buffer that
+        // turns out too small costs one more launch (the first call on a new field, typically).
+        if (int rc = ensure(ctx, ctx->sweep, sweep_scratch_bytes(sp))) return rc;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const size_t cap = std::min<size_t>(ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
+            VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
+            VTMC_HIP(ctx, launch_sweep(sp, ctx->tables, ctx->sweep.p, (uint32_t *)ctx->offsets.p, cap, ctx->tris.p, ctx->n_cus,
+                                       n_volumes, (uint32_t *)ctx->volcounts.p, ctx->tune, stream));
+            VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
+            VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->sweep.p, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            VTMC_HIP(ctx, hipStreamSynchronize(stream));
+            if (ctx->h_totals[kCtrlError])
+                return fail(ctx, VTMC_ERR_DEVICE, "sweep kernel: a chained-scan wait timed out (predecessor brick never published)");
+            const uint64_t T = ((uint64_t)ctx->h_totals[kCtrlTotalHi] << 32) | ctx->h_totals[kCtrlTotalLo];
+            if (T > 0x7fffffffull) return fail(ctx, VTMC_ERR_TOO_LARGE, "%llu triangles exceed the int32 range of the ABI", (unsigned long long)T);
+            T_found = (int64_t)T;
+            if ((size_t)T <= cap) break;
+            if (attempt == 1) return fail(ctx, VTMC_ERR_DEVICE, "triangle buffer still too small after growing");
+            const size_t want = (size_t)T + (size_t)T / 8 + 1024;
+            if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * want)) return rc;
+        }
+        float ms = 0;
+        VTMC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]));
+        ctx->stage_ms[0] = ms;
+        ctx->stage_ms[1] = 0;
+        ctx->stage_ms[2] = 0;
+        ctx->stage_ms[3] = ms;
+    } else {
     const int n_tiles = (B + kScanTile - 1) / kScanTile;
     if (int rc = ensure(ctx, ctx->counts, sizeof(uint32_t) * (size_t)B)) return rc;
-    if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
     if (int rc = ensure(ctx, ctx->active, sizeof(int32_t) * (size_t)B)) return rc;
     if (int rc = ensure(ctx, ctx->partials, sizeof(uint32_t) * 2 * (size_t)n_tiles)) return rc;
     if (int rc = ensure(ctx, ctx->totals, sizeof(uint32_t) * (64 + kQueueWords))) return rc;  // {T, nActive}, then the emit kernel's ticket counters
-    if (int rc = ensure(ctx, ctx->volcounts, sizeof(uint32_t) * 2 * (size_t)std::max(n_volumes, 1))) return rc;
     uint8_t *d_cases = nullptr;
     if (flags & VTMC_FLAG_WANT_CASES) {
         if (int rc = ensure(ctx, ctx->cases, (size_t)B * 512)) return rc;
         d_cases = (uint8_t *)ctx->cases.p;
     }
-    if (!ctx->tris.p)
-        if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * ((size_t)1 << 20))) return rc;
-
-    const bool dense = !sp.list && sp.sx == 1 && sp.nx >= 32 && !(flags & (VTMC_FLAG_WANT_CASES | VTMC_FLAG_NO_DENSE_PATH));
 
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
-    if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, stream));
+    if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, ctx->tune.classify_ablate, stream));
     else VTMC_HIP(ctx, launch_classify_blocks(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_cases, ctx->n_cus, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
     VTMC_HIP(ctx, launch_scan((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p,
@@ -158,6 +190,7 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
         VTMC_HIP(ctx, hipStreamSynchronize(stream));
         const uint32_t T = ctx->h_totals[0];
         if (T > 0x7fffffffu) return fail(ctx, VTMC_ERR_TOO_LARGE, "%u triangles exceed the int32 range of the ABI", T);
+        T_found = T;
         if ((size_t)T <= cap) break;
         if (attempt == 1) return fail(ctx, VTMC_ERR_DEVICE, "triangle buffer still too small after growing");
         // grow (with head-room so a slowly changing field does not regrow every frame) and redo the emit stage
@@ -173,12 +206,13 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
     ctx->stage_ms[1] = b;
     ctx->stage_ms[2] = c;
     ctx->stage_ms[3] = a + b + c;
+    }
 
     ctx->has_result = true;
     ctx->last_space = sp;
     ctx->last_blocks = B;
     ctx->last_volumes = n_volumes;
-    ctx->last_tris = ctx->h_totals[0];
+    ctx->last_tris = T_found;
     if (tri_count) *tri_count = ctx->last_tris;
     return VTMC_OK;
 }
@@ -256,7 +290,7 @@ int32_t vtmc_create(int32_t device, vtmc_ctx **out_ctx)
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (auto &ev : ctx->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipHostMalloc((void **)&ctx->h_totals, 2 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+    if ((e = hipHostMalloc((void **)&ctx->h_totals, kCtrlWords * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
 
     // tables: VoxelTerrain.cs:151-156 uploads three int tables; here the packed 2 KB vert table and a
@@ -283,7 +317,7 @@ int32_t vtmc_destroy(vtmc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->d_vert, &ctx->d_trinum, &ctx->counts, &ctx->offsets, &ctx->active, &ctx->partials, &ctx->totals,
-                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins})
+                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->sweep})
         release(*b);
     if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
     for (auto &ev : ctx->ev)
@@ -494,7 +528,9 @@ int32_t vtmc_reserve_triangles(vtmc_ctx *ctx, int64_t capacity)
     if (capacity < 0 || capacity > 0x7fffffffll) return fail(ctx, VTMC_ERR_INVALID_ARG, "capacity out of range");
     VTMC_HIP(ctx, hipSetDevice(ctx->device));
     ctx->has_result = false;  // the old triangle buffer may be released
-    return ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * (size_t)std::max<int64_t>(capacity, 1));
+    const size_t bytes = sizeof(vtmc_triangle) * (size_t)std::max<int64_t>(capacity, 1);
+    if (ctx->tris.p && ctx->tris.bytes > std::max<size_t>(bytes, 256)) release(ctx->tris);  // exact size: shrinking is allowed
+    return ensure(ctx, ctx->tris, bytes);
 }
 
 int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4])
@@ -509,13 +545,15 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
 {
     if (!ctx || !key) return VTMC_ERR_INVALID_ARG;
     const std::string k(key);
-    if (k == "emit_version") ctx->tune.emit_version = value;
-    else if (k == "emit_fast_math") ctx->tune.emit_fast_math = value;
+    if (k == "emit_fast_math") ctx->tune.emit_fast_math = value;
     else if (k == "emit_sub_log2") ctx->tune.emit_sub_log2 = value < 0 ? 0 : (value > 4 ? 4 : value);
     else if (k == "emit_dynamic") ctx->tune.emit_dynamic = value;
     else if (k == "emit_ablate") ctx->tune.emit_ablate = value;
+    else if (k == "classify_ablate") ctx->tune.classify_ablate = value;
     else if (k == "emit_group_log2") ctx->tune.emit_group_log2 = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (k == "emit_wgs_per_cu") ctx->tune.emit_wgs_per_cu = value;
+    else if (k == "sweep") ctx->tune.sweep = value;
+    else if (k == "sweep_wgs_per_cu") ctx->tune.sweep_wgs_per_cu = value;
     else return fail(ctx, VTMC_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
     return VTMC_OK;
 }
