@@ -169,6 +169,58 @@ int32_t vtmc_density_fill_device(vtmc_ctx *ctx, const vtmc_density_params *param
                                  int64_t stride_x, int64_t stride_y, int64_t stride_z,
                                  int64_t volume_stride, float *d_out, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Device-resident terrain: the density grid of VoxelTerrain and its Update() on the GPU.
+ * Replaces _voxelSamples (VoxelTerrain.cs:42,145), the per-sample CSG loop of Update
+ * (VoxelTerrain.cs:284-305), the dirty-block selection (VoxelTerrain.cs:307-317) and the hand-off to
+ * BatchUpdate (VoxelTerrain.cs:321-324) without the grid ever crossing PCIe.
+ * ------------------------------------------------------------------------------------------ */
+
+#define VTMC_MOD_PLANE 0     /* TerrainModifier.cs:38-65   f = _height - y            p[0] = _height */
+#define VTMC_MOD_SPHERE 1    /* TerrainModifier.cs:70-91   f = _radius - |pos - c|    p[0..2] = _center, p[3] = _radius */
+#define VTMC_MOD_CYLINDER 2  /* TerrainModifier.cs:96-152  p[0..2] = _axisStart, p[3..5] = _axisDir (normalised),
+                                                           p[6] = _axisLength, p[7] = _radius */
+
+/* One queued TerrainModifier (TerrainModifier.cs:19-33).  lower / upper are the values the C#
+ * LowerBound / UpperBound properties return (world space): the shim copies them, so Unity's
+ * Vector3.ProjectOnPlane stays on the C# side. */
+typedef struct vtmc_modifier {
+    int32_t kind;
+    int32_t add_or_erode; /* 1: add (union, max), 0: erode (difference, clamped min of the negation) */
+    float lower[3];
+    float upper[3];
+    float p[8];
+} vtmc_modifier;
+
+/* Replaces the grid allocation + fill of VoxelTerrain.Init (VoxelTerrain.cs:121-149): a
+ * (width+2, elevation+2, height+2)-sample grid in HBM, every sample a "void" value in [-2,-1].
+ * The reference draws voidDensity / fullDensity from UnityEngine.Random on every read
+ * (VoxelTerrain.cs:50-51); here they are a counter-based hash of (seed, event, sample, draw) with
+ * the same ranges and the same number of draws, so results are reproducible.  Errors as the
+ * reference's: dims not a multiple of 8, more than 1025 samples per axis (VoxelTerrain.cs:138-142). */
+int32_t vtmc_terrain_init(vtmc_ctx *ctx, int32_t width, int32_t elevation, int32_t height, float voxel_scale,
+                          const float terrain_origin[3], uint64_t seed);
+
+/* Replaces VoxelTerrain.Update (VoxelTerrain.cs:262-325) for a queue of n_mods modifiers, applied
+ * in order: AABB -> sample range (floor / ceil, clamped to [0, dim+1]), per-sample density write,
+ * union of dirty blocks (a block is dirty on an axis when up >= 8b && low <= 8b+8), then
+ * BatchUpdate on that set.  The dirty list is ordered by bx + nbx*(by + nby*bz) (the reference's
+ * HashSet order is arbitrary); `block` of a triangle indexes it.  *n_dirty_blocks and *tri_count may
+ * be NULL.  Triangles are read with vtmc_read_triangles / vtmc_device_results as after any extract. */
+int32_t vtmc_terrain_update(vtmc_ctx *ctx, const vtmc_modifier *mods, int32_t n_mods, int32_t *n_dirty_blocks,
+                            int32_t *tri_count);
+
+/* The dirty list of the last vtmc_terrain_update: n (bx,by,bz) triples (_nextUpdateblocks,
+ * VoxelTerrain.cs:321). */
+int32_t vtmc_terrain_dirty_blocks(vtmc_ctx *ctx, int32_t *dst, int32_t capacity_blocks, int32_t *n_blocks);
+
+/* Copies the density grid to the host: dst[x*stride_x + y*stride_y + z*stride_z] (element strides;
+ * a C# float[W+2,E+2,H+2] is ((E+2)*(H+2), H+2, 1)).  Parity / debugging / persistence. */
+int32_t vtmc_terrain_read_samples(vtmc_ctx *ctx, float *dst, int64_t stride_x, int64_t stride_y, int64_t stride_z);
+
+/* Device pointer + element strides of the grid (x fastest), for GPU-resident callers. */
+int32_t vtmc_terrain_device_grid(vtmc_ctx *ctx, const float **d_samples, int64_t strides[3], int32_t dims[3]);
+
 /* Library / build identification: "vtmc <version> gfx950". */
 const char *vtmc_version(void);
 

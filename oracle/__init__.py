@@ -20,6 +20,12 @@ TRI_DTYPE = np.dtype([("p0", "<f4", 3), ("p1", "<f4", 3), ("p2", "<f4", 3),
 assert TRI_DTYPE.itemsize == 76  # VoxelTerrain.cs:36
 
 
+class Modifier(ctypes.Structure):
+    """TerrainModifier.cs:19-33 flattened (same layout as vtmc_modifier of include/vtmc.h)."""
+    _fields_ = [("kind", ctypes.c_int32), ("add_or_erode", ctypes.c_int32), ("lower", ctypes.c_float * 3),
+                ("upper", ctypes.c_float * 3), ("p", ctypes.c_float * 8)]
+
+
 class DensityParams(ctypes.Structure):
     _fields_ = [("seed", ctypes.c_uint64), ("frequency", ctypes.c_float), ("octaves", ctypes.c_int32),
                 ("lacunarity", ctypes.c_float), ("gain", ctypes.c_float),
@@ -27,7 +33,7 @@ class DensityParams(ctypes.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("mc_oracle.c", "density_ref.c", "mc_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("mc_oracle.c", "density_ref.c", "terrain_ref.c", "mc_oracle.h", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "volumetricterrain_amd", "csrc", "mc_tables_packed.h"))
     stale = force or not os.path.exists(_SO) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs if os.path.exists(s))
@@ -57,6 +63,9 @@ def lib():
         L.vto_density_permutation.argtypes = [ctypes.c_uint64, vp]
         L.vto_density_fill.argtypes = [ctypes.POINTER(DensityParams), i32, i32, i32, i32, i32, i32,
                                        i64, i64, i64, vp]
+        L.vto_terrain_fill.argtypes = [vp, i32, i32, i32, ctypes.c_uint64]
+        L.vto_terrain_update.argtypes = [vp, i32, i32, i32, f32, vp, ctypes.c_uint64, ctypes.c_uint32, vp, i32, vp]
+        L.vto_terrain_update.restype = i64
         _lib = L
     return _lib
 
@@ -192,3 +201,89 @@ def permutation(seed=1337):
     perm = np.zeros(256, np.uint8)
     lib().vto_density_permutation(seed, _p(perm))
     return perm
+
+
+# -- terrain: VoxelTerrain.Init fill + Update density write + dirty blocks (oracle/terrain_ref.c) ----
+FLT_LOWEST = -3.4028234663852886e38  # float.MinValue
+
+
+def plane_modifier(height, low, up, add=True):
+    """PlaneModifier (TerrainModifier.cs:38-65): bounds (_low.x, float.MinValue, _low.y) .. (_up.x, _height + 1, _up.y)."""
+    m = Modifier(0, int(add))
+    m.lower[:] = (low[0], FLT_LOWEST, low[1])
+    m.upper[:] = (up[0], np.float32(height) + np.float32(1), up[1])
+    m.p[0] = height
+    return m
+
+
+def sphere_modifier(center, radius, add=True):
+    """SphereModifier (TerrainModifier.cs:70-91): bounds center -+ radius (FP32)."""
+    m = Modifier(1, int(add))
+    c, r = np.asarray(center, np.float32), np.float32(radius)
+    m.lower[:] = tuple(c - r)
+    m.upper[:] = tuple(c + r)
+    m.p[0:4] = (c[0], c[1], c[2], r)
+    return m
+
+
+def cylinder_modifier(start, direction, length, radius, add=True):
+    """CylinderModifier (TerrainModifier.cs:96-152).  Bounds follow the C# properties: per axis the
+    start or end point shifted by radius * ProjectOnPlane(unit axis, _axisDir), all FP32."""
+    f = np.float32
+    s = np.asarray(start, f)
+    d = np.asarray(direction, f)
+
+    def dot(a, b):  # Vector3.Dot, FP32, left to right
+        return f(f(f(a[0] * b[0]) + f(a[1] * b[1])) + f(a[2] * b[2]))
+
+    d = (d / f(np.sqrt(dot(d, d)))).astype(f)  # dir.normalized
+    end = (s + d * f(length)).astype(f)
+
+    def proj(v):  # Vector3.ProjectOnPlane(v, n) = v - n * Dot(v, n) / Dot(n, n)
+        v = np.asarray(v, f)
+        return (v - d * (dot(v, d) / dot(d, d))).astype(f)
+
+    m = Modifier(2, int(add))
+    lo, hi = [], []
+    for a in range(3):
+        neg = np.zeros(3, f)
+        neg[a] = -1
+        pos = np.zeros(3, f)
+        pos[a] = 1
+        lo.append(((s if d[a] > 0 else end) + proj(neg) * f(radius))[a])
+        hi.append(((s if d[a] < 0 else end) + proj(pos) * f(radius))[a])
+    m.lower[:] = tuple(lo)
+    m.upper[:] = tuple(hi)
+    m.p[0:8] = (s[0], s[1], s[2], d[0], d[1], d[2], length, radius)
+    return m
+
+
+def modifier_array(mods):
+    arr = (Modifier * max(len(mods), 1))()
+    for i, m in enumerate(mods):
+        arr[i] = m
+    return arr
+
+
+class Terrain:
+    """CPU twin of the device-resident terrain: grid indexed [x, y, z], x fastest in memory."""
+
+    def __init__(self, width, elevation, height, voxel_scale=1.0, origin=(0.0, 0.0, 0.0), seed=1):
+        self.dims = (width, elevation, height)
+        self.scale, self.seed, self.events = float(voxel_scale), int(seed), 0
+        self.origin = np.asarray(origin, np.float32)
+        self._mem = np.empty((height + 2, elevation + 2, width + 2), np.float32)
+        self.grid = self._mem.transpose(2, 1, 0)
+        lib().vto_terrain_fill(_p(self._mem), width + 2, elevation + 2, height + 2, self.seed)
+
+    def update(self, mods):
+        """Applies the queue; returns the dirty list ordered by block id, as (n, 3) int32."""
+        w, e, h = self.dims
+        nb = (w // 8, e // 8, h // 8)
+        dirty = np.zeros(nb[0] * nb[1] * nb[2], np.uint8)
+        arr = modifier_array(mods)
+        lib().vto_terrain_update(_p(self._mem), w, e, h, self.scale, _p(self.origin), self.seed, self.events,
+                                 ctypes.cast(arr, ctypes.c_void_p), len(mods), _p(dirty))
+        self.events += len(mods)
+        ids = np.flatnonzero(dirty)
+        return np.stack([ids % nb[0], (ids // nb[0]) % nb[1], ids // (nb[0] * nb[1])], axis=1).astype(np.int32)

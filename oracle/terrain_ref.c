@@ -1,0 +1,138 @@
+/*
+ * terrain_ref.c -- CPU restatement of VoxelTerrain.Init's grid fill and VoxelTerrain.Update
+ * (density write + dirty-block selection) and of the Plane / Sphere / Cylinder modifiers.
+ *
+ * TEST INFRASTRUCTURE ONLY (see mc_oracle.h): the checker of volumetricterrain_amd/csrc/terrain.hip.
+ *
+ * Follows, line by line (paths relative to /root/reference/Unity-Project/Assets/Scripts/):
+ *   VoxelTerrain.cs:145-149   grid of (W+2, E+2, H+2) samples filled with voidDensity
+ *   VoxelTerrain.cs:273-281   AABB -> sample indices: (world - TerrainOrigin) / _voxelScale, floor / ceil, clamps
+ *   VoxelTerrain.cs:284-305   per-sample write: add = Max(S, Clamp(Q, void, full));
+ *                             erode = Clamp(Min(S, -Clamp(Q, void, full)), void, full)
+ *   VoxelTerrain.cs:307-317   dirty blocks: up >= 8b && low <= 8b + 8 on every axis (the literal triple loop)
+ *   TerrainModifier.cs:59-62, :79-82, :143-149   QueryDensity of plane, sphere, cylinder
+ *
+ * PARITY STATUS: unpinned against an execution of the reference for the clamp values only:
+ * voidDensity / fullDensity are UnityEngine.Random draws on every read (VoxelTerrain.cs:50-51), a
+ * stream that cannot be replayed.  Both this file and the HIP kernel replace it with the same
+ * counter-based hash (ranges [-2,-1) and [1,2), same number of draws per sample); everything
+ * else -- operation order, FP32 arithmetic, correctly rounded sqrt -- is the reference's.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    int32_t kind;         /* 0 plane, 1 sphere, 2 cylinder */
+    int32_t add_or_erode; /* TerrainModifier.AddOrErode */
+    float lower[3];       /* LowerBound */
+    float upper[3];       /* UpperBound */
+    float p[8];           /* plane: _height; sphere: _center, _radius; cylinder: _axisStart, _axisDir, _axisLength, _radius */
+} vto_modifier;
+
+static float uniform01(uint64_t seed, uint32_t event, uint64_t sample, uint32_t draw)
+{
+    uint64_t z = (seed ^ ((uint64_t)event << 40) ^ (sample << 2) ^ (uint64_t)draw) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(uint32_t)(z >> 40) * 5.9604644775390625e-08f;
+}
+
+static float clampf(float v, float lo, float hi) /* Mathf.Clamp */
+{
+    if (v < lo) v = lo;
+    else if (v > hi) v = hi;
+    return v;
+}
+
+static float query_density(const vto_modifier *m, float px, float py, float pz)
+{
+    if (m->kind == 0) return m->p[0] - py; /* TerrainModifier.cs:59-62 */
+    if (m->kind == 1) {                    /* TerrainModifier.cs:79-82 */
+        float dx = px - m->p[0], dy = py - m->p[1], dz = pz - m->p[2];
+        return m->p[3] - sqrtf(dx * dx + dy * dy + dz * dz); /* Vector3.magnitude = Mathf.Sqrt(x*x + y*y + z*z) */
+    }
+    {   /* TerrainModifier.cs:143-149 */
+        float sx = px - m->p[0], sy = py - m->p[1], sz = pz - m->p[2];
+        float proj = sx * m->p[3] + sy * m->p[4] + sz * m->p[5]; /* Vector3.Dot */
+        float sq = sx * sx + sy * sy + sz * sz;                  /* sqrMagnitude */
+        float c = m->p[7] - sqrtf(sq - proj * proj);
+        float b = m->p[6] - proj;
+        float r = proj; /* Mathf.Min(params float[]): `if (values[i] < num) num = values[i]` */
+        if (b < r) r = b;
+        if (c < r) r = c;
+        return r;
+    }
+}
+
+static int32_t floor_to_int(float v)
+{
+    float f = floorf(v);
+    return f <= -2147483648.0f ? INT32_MIN : (f >= 2147483648.0f ? INT32_MAX : (int32_t)f);
+}
+static int32_t ceil_to_int(float v)
+{
+    float f = ceilf(v);
+    return f <= -2147483648.0f ? INT32_MIN : (f >= 2147483648.0f ? INT32_MAX : (int32_t)f);
+}
+
+/* VoxelTerrain.cs:145-149.  grid[x + dimx*(y + dimy*z)], dims = cells + 2. */
+void vto_terrain_fill(float *grid, int32_t dimx, int32_t dimy, int32_t dimz, uint64_t seed)
+{
+    int64_t n = (int64_t)dimx * dimy * dimz;
+    for (int64_t i = 0; i < n; ++i) grid[i] = uniform01(seed, 0u, (uint64_t)i, 0u) - 2.0f;
+}
+
+/* VoxelTerrain.cs:262-325 for a queue of n_mods modifiers.  `first_event` = number of modifiers
+ * applied since Init before this call.  dirty (nbx*nby*nbz bytes, indexed bx + nbx*(by + nby*bz))
+ * receives 1 for every block of the union.  Returns the number of dirty blocks. */
+int64_t vto_terrain_update(float *grid, int32_t width, int32_t elevation, int32_t height, float voxel_scale,
+                           const float origin[3], uint64_t seed, uint32_t first_event, const vto_modifier *mods,
+                           int32_t n_mods, uint8_t *dirty)
+{
+    const int32_t dimx = width + 2, dimy = elevation + 2;
+    const int32_t nbx = width / 8, nby = elevation / 8, nbz = height / 8;
+    memset(dirty, 0, (size_t)nbx * nby * nbz);
+    for (int32_t i = 0; i < n_mods; ++i) {
+        const vto_modifier *m = &mods[i];
+        const uint32_t event = first_event + (uint32_t)i + 1u;
+        int32_t low[3], up[3];
+        const int32_t top[3] = {width + 1, elevation + 1, height + 1};
+        for (int a = 0; a < 3; ++a) {
+            int32_t l = floor_to_int((m->lower[a] - origin[a]) / voxel_scale);
+            int32_t u = ceil_to_int((m->upper[a] - origin[a]) / voxel_scale);
+            low[a] = l > 0 ? l : 0;
+            up[a] = u < top[a] ? u : top[a];
+        }
+        for (int64_t x = low[0]; x <= up[0]; x++)
+            for (int64_t y = low[1]; y <= up[1]; y++)
+                for (int64_t z = low[2]; z <= up[2]; z++) {
+                    const float px = (float)x * voxel_scale + origin[0];
+                    const float py = (float)y * voxel_scale + origin[1];
+                    const float pz = (float)z * voxel_scale + origin[2];
+                    const uint64_t s = (uint64_t)x + (uint64_t)dimx * ((uint64_t)y + (uint64_t)dimy * (uint64_t)z);
+                    const float void0 = uniform01(seed, event, s, 0u) - 2.0f;
+                    const float full0 = uniform01(seed, event, s, 1u) + 1.0f;
+                    const float md = clampf(query_density(m, px, py, pz), void0, full0);
+                    if (m->add_or_erode) {
+                        grid[s] = grid[s] > md ? grid[s] : md;
+                    } else {
+                        const float void1 = uniform01(seed, event, s, 2u) - 2.0f;
+                        const float full1 = uniform01(seed, event, s, 3u) + 1.0f;
+                        const float minus_md = -md;
+                        grid[s] = clampf(grid[s] < minus_md ? grid[s] : minus_md, void1, full1);
+                    }
+                }
+        for (int32_t x = 0; x < nbx; x++)
+            for (int32_t y = 0; y < nby; y++)
+                for (int32_t z = 0; z < nbz; z++)
+                    if ((up[0] >= x * 8 && low[0] <= x * 8 + 8) && (up[1] >= y * 8 && low[1] <= y * 8 + 8) &&
+                        (up[2] >= z * 8 && low[2] <= z * 8 + 8))
+                        dirty[(size_t)x + (size_t)nbx * ((size_t)y + (size_t)nby * z)] = 1;
+    }
+    int64_t n = 0;
+    for (size_t i = 0; i < (size_t)nbx * nby * nbz; ++i) n += dirty[i];
+    return n;
+}

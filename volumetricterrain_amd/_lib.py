@@ -27,7 +27,18 @@ SYMBOLS = [
     "vtmc_extract_grid", "vtmc_extract_grid_sharded", "vtmc_read_triangles", "vtmc_read_cases",
     "vtmc_last_counts", "vtmc_extract_volumes_device", "vtmc_device_results",
     "vtmc_reserve_triangles", "vtmc_last_stage_ms", "vtmc_set_tuning", "vtmc_density_fill_device",
+    "vtmc_terrain_init", "vtmc_terrain_update", "vtmc_terrain_dirty_blocks", "vtmc_terrain_read_samples",
+    "vtmc_terrain_device_grid",
 ]
+
+MOD_PLANE, MOD_SPHERE, MOD_CYLINDER = 0, 1, 2
+
+
+class Modifier(ctypes.Structure):
+    """vtmc_modifier: one queued TerrainModifier (TerrainModifier.cs:19-33), bounds as the C#
+    LowerBound / UpperBound properties return them."""
+    _fields_ = [("kind", ctypes.c_int32), ("add_or_erode", ctypes.c_int32), ("lower", ctypes.c_float * 3),
+                ("upper", ctypes.c_float * 3), ("p", ctypes.c_float * 8)]
 
 
 class VolumeBatch(ctypes.Structure):
@@ -88,6 +99,11 @@ def load():
     L.vtmc_set_tuning.argtypes = [vp, ctypes.c_char_p, i32]
     L.vtmc_density_fill_device.argtypes = [vp, P(DensityParams), vp, i32, i32, i32, i32,
                                            i64, i64, i64, i64, vp, vp]
+    L.vtmc_terrain_init.argtypes = [vp, i32, i32, i32, ctypes.c_float, P(ctypes.c_float * 3), ctypes.c_uint64]
+    L.vtmc_terrain_update.argtypes = [vp, vp, i32, P(i32), P(i32)]
+    L.vtmc_terrain_dirty_blocks.argtypes = [vp, vp, i32, P(i32)]
+    L.vtmc_terrain_read_samples.argtypes = [vp, vp, i64, i64, i64]
+    L.vtmc_terrain_device_grid.argtypes = [vp, P(vp), P(i64 * 3), P(i32 * 3)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int:

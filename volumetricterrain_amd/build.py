@@ -12,7 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvtmc.so")
-SOURCES = ["vtmc_api.hip", "classify_kernels.hip", "emit_kernels.hip", "sweep_kernels.hip", "density.hip"]
+SOURCES = ["vtmc_api.hip", "classify_kernels.hip", "emit_kernels.hip", "sweep_kernels.hip", "terrain.hip", "density.hip"]
 HEADERS = ["vtmc_internal.h", "mc_device.h", "emit_device.h", "mc_tables_packed.h", os.path.join("..", "..", "include", "vtmc.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function"]

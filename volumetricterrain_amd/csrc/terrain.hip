@@ -1,0 +1,109 @@
+// terrain.hip -- device-resident density grid with the reference's CSG write semantics: the
+// "density-field sampler" stage of the path (hand-written gfx950 / CDNA4).
+//
+// Replaces (paths relative to /root/reference/Unity-Project/Assets/Scripts/):
+//   VoxelTerrain.cs:145-149  Init: grid filled with "void" values            -> terrain_fill_kernel
+//   VoxelTerrain.cs:284-305  Update: per-sample QueryDensity + clamp + max / min -> terrain_modify_kernel
+//   TerrainModifier.cs:59-62 (plane), :79-82 (sphere), :143-149 (cylinder)  -> query_density
+// One lane per sample of the modifier's AABB, x fastest (the grid is x fastest), so a wave reads and
+// writes contiguous 256-byte row segments.  HBM-bound: 8 bytes per touched sample, a handful of
+// FP32 operations in the reference's order (library built with -ffp-contract=off; sqrt is the
+// correctly rounded one, as Mathf.Sqrt = (float)Math.Sqrt is).
+//
+// voidDensity / fullDensity (VoxelTerrain.cs:50-51) are FRESH random numbers in [-2,-1] / [1,2] on
+// every read in the reference (UnityEngine.Random: a stream nobody can replay).  Here they are a
+// counter-based hash of (seed, event, sample index, draw index) -- same ranges, same number of
+// draws per sample (2 per add, 4 per erode, 1 per Init sample), deterministic; the CPU oracle
+// restates the same hash (oracle/terrain_ref.c).
+#include "vtmc_internal.h"
+
+namespace vtmc {
+
+__host__ __device__ __forceinline__ float terrain_uniform(uint64_t seed, uint32_t event, uint64_t sample, uint32_t draw)
+{
+    uint64_t z = (seed ^ ((uint64_t)event << 40) ^ (sample << 2) ^ (uint64_t)draw) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(uint32_t)(z >> 40) * 5.9604644775390625e-08f;  // 24 bits * 2^-24: exact, in [0,1)
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi)  // Mathf.Clamp
+{
+    if (v < lo) v = lo;
+    else if (v > hi) v = hi;
+    return v;
+}
+
+__device__ __forceinline__ float query_density(const TerrainModifierArgs &m, float px, float py, float pz)
+{
+    if (m.kind == 0) return m.p[0] - py;  // PlaneModifier: _height - pos.y
+    if (m.kind == 1) {                    // SphereModifier: _radius - (pos - _center).magnitude
+        const float dx = px - m.p[0], dy = py - m.p[1], dz = pz - m.p[2];
+        return m.p[3] - __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+    }
+    // CylinderModifier: Min(projLength, _axisLength - projLength, _radius - Sqrt(|start2pos|^2 - projLength^2))
+    const float sx = px - m.p[0], sy = py - m.p[1], sz = pz - m.p[2];
+    const float proj = sx * m.p[3] + sy * m.p[4] + sz * m.p[5];
+    const float sq = sx * sx + sy * sy + sz * sz;
+    const float c = m.p[7] - __builtin_sqrtf(sq - proj * proj);
+    float r = proj;  // Mathf.Min(params): `if (v < min) min = v`, so a NaN candidate is skipped
+    const float b = m.p[6] - proj;
+    if (b < r) r = b;
+    if (c < r) r = c;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void terrain_fill_kernel(float *__restrict__ grid, long long n, uint64_t seed)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        grid[i] = terrain_uniform(seed, 0u, (uint64_t)i, 0u) - 2.0f;  // voidDensity
+}
+
+// launch shape: 64 x 4 threads = 4 row segments of 64 samples; grid = (x segments, row quads, z planes)
+__global__ __launch_bounds__(256) void terrain_modify_kernel(float *__restrict__ grid, TerrainShape sh, TerrainModifierArgs m)
+{
+    const int ix = blockIdx.x * 64 + threadIdx.x, iy = blockIdx.y * 4 + threadIdx.y, iz = blockIdx.z;
+    if (ix >= m.dx || iy >= m.dy) return;
+    const int x = m.lx + ix, y = m.ly + iy, z = m.lz + iz;
+    // worldPos = new Vector3(x, y, z) * _voxelScale + TerrainOrigin (VoxelTerrain.cs:290)
+    const float px = (float)x * sh.scale + sh.origin[0];
+    const float py = (float)y * sh.scale + sh.origin[1];
+    const float pz = (float)z * sh.scale + sh.origin[2];
+    const uint64_t sample = (uint64_t)x + (uint64_t)sh.dim_x * ((uint64_t)y + (uint64_t)sh.dim_y * (uint64_t)z);
+    const float void0 = terrain_uniform(sh.seed, m.event, sample, 0u) - 2.0f;
+    const float full0 = terrain_uniform(sh.seed, m.event, sample, 1u) + 1.0f;
+    const float md = clampf(query_density(m, px, py, pz), void0, full0);
+    const float s = grid[sample];
+    float r;
+    if (m.add_or_erode) {
+        r = s > md ? s : md;  // Mathf.Max(S, md)
+    } else {
+        const float void1 = terrain_uniform(sh.seed, m.event, sample, 2u) - 2.0f;
+        const float full1 = terrain_uniform(sh.seed, m.event, sample, 3u) + 1.0f;
+        const float minus_md = -md;
+        r = clampf(s < minus_md ? s : minus_md, void1, full1);  // Clamp(Min(S, -md), void, full)
+    }
+    grid[sample] = r;
+}
+
+hipError_t launch_terrain_fill(float *grid, long long n, uint64_t seed, int n_cus, hipStream_t stream)
+{
+    long long wgs = (n + 255) / 256;
+    if (wgs > (long long)n_cus * 16) wgs = (long long)n_cus * 16;
+    if (wgs < 1) wgs = 1;
+    hipLaunchKernelGGL(terrain_fill_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, grid, n, seed);
+    return hipGetLastError();
+}
+
+hipError_t launch_terrain_modify(float *grid, const TerrainShape &sh, const TerrainModifierArgs &m, hipStream_t stream)
+{
+    if (m.dx <= 0 || m.dy <= 0 || m.dz <= 0) return hipSuccess;
+    if (m.dz > 65535 || (m.dy + 3) / 4 > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(terrain_modify_kernel, dim3((unsigned)((m.dx + 63) / 64), (unsigned)((m.dy + 3) / 4), (unsigned)m.dz),
+                       dim3(64, 4, 1), 0, stream, grid, sh, m);
+    return hipGetLastError();
+}
+
+}  // namespace vtmc

@@ -15,6 +15,8 @@
 #include "vtmc_internal.h"
 
 #include <algorithm>
+#include <climits>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -52,6 +54,12 @@ struct vtmc_ctx {
     int last_volumes = 0;
     int64_t last_tris = 0;
     Tuning tune;
+    // device-resident terrain (vtmc_terrain_*)
+    DevBuf terrain;
+    TerrainShape tshape{};
+    bool has_terrain = false;
+    uint32_t terrain_events = 0;
+    std::vector<int32_t> dirty;  // (bx,by,bz) of the last vtmc_terrain_update
     uint64_t perm_seed = 0;
     bool perm_valid = false;
     std::string err;
@@ -317,7 +325,7 @@ int32_t vtmc_destroy(vtmc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->d_vert, &ctx->d_trinum, &ctx->counts, &ctx->offsets, &ctx->active, &ctx->partials, &ctx->totals,
-                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->sweep})
+                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->sweep, &ctx->terrain})
         release(*b);
     if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
     for (auto &ev : ctx->ev)
@@ -555,6 +563,185 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     else if (k == "sweep") ctx->tune.sweep = value;
     else if (k == "sweep_wgs_per_cu") ctx->tune.sweep_wgs_per_cu = value;
     else return fail(ctx, VTMC_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
+    return VTMC_OK;
+}
+
+int32_t vtmc_terrain_init(vtmc_ctx *ctx, int32_t width, int32_t elevation, int32_t height, float voxel_scale,
+                          const float terrain_origin[3], uint64_t seed)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!terrain_origin) return fail(ctx, VTMC_ERR_INVALID_ARG, "terrain_origin is null");
+    if (int rc = check_dims(ctx, width, elevation, height)) return rc;
+    // VoxelTerrain.cs:141-142
+    if (width + 1 > 1025 || elevation + 1 > 1025 || height + 1 > 1025)
+        return fail(ctx, VTMC_ERR_DIMS, "too high resolution (exceeds 1025)");
+    if (!(voxel_scale > 0.0f)) return fail(ctx, VTMC_ERR_INVALID_ARG, "voxel_scale must be positive");
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->has_terrain = false;
+    ctx->has_result = false;
+    TerrainShape sh{};
+    sh.dim_x = width + 2;
+    sh.dim_y = elevation + 2;
+    sh.dim_z = height + 2;
+    sh.scale = voxel_scale;
+    memcpy(sh.origin, terrain_origin, sizeof sh.origin);
+    sh.seed = seed;
+    const long long n = (long long)sh.dim_x * sh.dim_y * sh.dim_z;
+    if (int rc = ensure(ctx, ctx->terrain, sizeof(float) * (size_t)n)) return rc;
+    VTMC_HIP(ctx, launch_terrain_fill((float *)ctx->terrain.p, n, seed, ctx->n_cus, ctx->stream));
+    VTMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tshape = sh;
+    ctx->terrain_events = 0;
+    ctx->dirty.clear();
+    ctx->has_terrain = true;
+    return VTMC_OK;
+}
+
+int32_t vtmc_terrain_update(vtmc_ctx *ctx, const vtmc_modifier *mods, int32_t n_mods, int32_t *n_dirty_blocks, int32_t *tri_count)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->has_terrain) return fail(ctx, VTMC_ERR_NO_RESULT, "terrain_update before terrain_init");
+    if (n_mods < 0 || (n_mods > 0 && !mods)) return fail(ctx, VTMC_ERR_INVALID_ARG, "mods is null or n_mods < 0");
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    const TerrainShape &sh = ctx->tshape;
+    const int W = sh.dim_x - 2, E = sh.dim_y - 2, H = sh.dim_z - 2;
+    const int nbx = W / 8, nby = E / 8, nbz = H / 8;
+    std::vector<uint8_t> mark((size_t)nbx * nby * nbz, 0);
+    size_t n_marked = 0;
+    auto floor_to_int = [](float v) {  // Mathf.FloorToInt, saturating
+        const float f = std::floor(v);
+        return f <= -2147483648.0f ? INT32_MIN : (f >= 2147483648.0f ? INT32_MAX : (int)f);
+    };
+    auto ceil_to_int = [](float v) {
+        const float f = std::ceil(v);
+        return f <= -2147483648.0f ? INT32_MIN : (f >= 2147483648.0f ? INT32_MAX : (int)f);
+    };
+    for (int32_t i = 0; i < n_mods; ++i) {
+        const vtmc_modifier &md = mods[i];
+        if (md.kind < VTMC_MOD_PLANE || md.kind > VTMC_MOD_CYLINDER) return fail(ctx, VTMC_ERR_INVALID_ARG, "modifier %d: unknown kind %d", i, md.kind);
+        // world -> sample index: (world - TerrainOrigin) / _voxelScale, floor / ceil, clamp (VoxelTerrain.cs:273-281)
+        int low[3], up[3];
+        const int top[3] = {W + 1, E + 1, H + 1};
+        for (int a = 0; a < 3; ++a) {
+            low[a] = std::max(floor_to_int((md.lower[a] - sh.origin[a]) / sh.scale), 0);
+            up[a] = std::min(ceil_to_int((md.upper[a] - sh.origin[a]) / sh.scale), top[a]);
+        }
+        TerrainModifierArgs a{};
+        a.kind = md.kind;
+        a.add_or_erode = md.add_or_erode ? 1 : 0;
+        memcpy(a.p, md.p, sizeof a.p);
+        a.lx = low[0];
+        a.ly = low[1];
+        a.lz = low[2];
+        a.dx = up[0] - low[0] + 1;
+        a.dy = up[1] - low[1] + 1;
+        a.dz = up[2] - low[2] + 1;
+        a.event = ++ctx->terrain_events;
+        if (a.dx > 0 && a.dy > 0 && a.dz > 0) VTMC_HIP(ctx, launch_terrain_modify((float *)ctx->terrain.p, sh, a, ctx->stream));
+        // dirty blocks: up >= 8b && low <= 8b + 8 on every axis (VoxelTerrain.cs:307-317), as index ranges
+        int b0[3], b1[3];
+        const int nb[3] = {nbx, nby, nbz};
+        bool any = true;
+        for (int k = 0; k < 3; ++k) {
+            // b <= up / 8 and b >= (low - 8) / 8 rounded up; the reference's loops leave an empty
+            // (low > up) AABB with its block tests, so the same arithmetic is used for it
+            const long long lo = (long long)low[k] - 8, hi = up[k];
+            long long f = lo <= 0 ? 0 : (lo + 7) / 8;
+            long long l = hi < 0 ? -1 : hi / 8;
+            if (l > nb[k] - 1) l = nb[k] - 1;
+            b0[k] = (int)f;
+            b1[k] = (int)l;
+            if (f > l) any = false;
+        }
+        if (any)
+            for (int bz = b0[2]; bz <= b1[2]; ++bz)
+                for (int by = b0[1]; by <= b1[1]; ++by)
+                    for (int bx = b0[0]; bx <= b1[0]; ++bx) {
+                        uint8_t &mk = mark[(size_t)bx + (size_t)nbx * ((size_t)by + (size_t)nby * bz)];
+                        n_marked += !mk;
+                        mk = 1;
+                    }
+    }
+    // _nextUpdateblocks (VoxelTerrain.cs:321), ordered by block id
+    ctx->dirty.clear();
+    ctx->dirty.reserve(n_marked * 3);
+    for (int bz = 0; bz < nbz; ++bz)
+        for (int by = 0; by < nby; ++by)
+            for (int bx = 0; bx < nbx; ++bx)
+                if (mark[(size_t)bx + (size_t)nbx * ((size_t)by + (size_t)nby * bz)]) {
+                    ctx->dirty.push_back(bx);
+                    ctx->dirty.push_back(by);
+                    ctx->dirty.push_back(bz);
+                }
+    if (n_dirty_blocks) *n_dirty_blocks = (int32_t)n_marked;
+    // BatchUpdate (VoxelTerrain.cs:322-323: only when the set is not empty) on the resident grid
+    BlockSpace sp = dense_space((const float *)ctx->terrain.p, W, E, H, 1, sh.dim_x, (int64_t)sh.dim_x * sh.dim_y, 1, 0);
+    int n_volumes = 1;
+    if (n_marked != mark.size()) {  // a proper subset: device block list; every block: the dense streaming path
+        if (int rc = ensure(ctx, ctx->list, sizeof(int32_t) * 3 * std::max<size_t>(n_marked, 1))) return rc;
+        if (n_marked > 0)
+            VTMC_HIP(ctx, hipMemcpyAsync(ctx->list.p, ctx->dirty.data(), sizeof(int32_t) * 3 * n_marked, hipMemcpyHostToDevice, ctx->stream));
+        sp.list = (const int *)ctx->list.p;
+        sp.n_blocks = (int)n_marked;
+        n_volumes = 0;
+    }
+    int64_t T = 0;
+    if (int rc = extract_core(ctx, sp, n_volumes, 0, ctx->stream, &T)) return rc;
+    if (tri_count) *tri_count = (int32_t)T;
+    return VTMC_OK;
+}
+
+int32_t vtmc_terrain_dirty_blocks(vtmc_ctx *ctx, int32_t *dst, int32_t capacity_blocks, int32_t *n_blocks)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->has_terrain) return fail(ctx, VTMC_ERR_NO_RESULT, "terrain_dirty_blocks before terrain_init");
+    const size_t n = ctx->dirty.size() / 3;
+    if (n_blocks) *n_blocks = (int32_t)n;
+    if (!dst) return VTMC_OK;  // size query
+    if ((size_t)std::max(capacity_blocks, 0) < n) return fail(ctx, VTMC_ERR_CAPACITY, "capacity %d < %zu dirty blocks", capacity_blocks, n);
+    if (n) memcpy(dst, ctx->dirty.data(), n * 3 * sizeof(int32_t));
+    return VTMC_OK;
+}
+
+int32_t vtmc_terrain_read_samples(vtmc_ctx *ctx, float *dst, int64_t stride_x, int64_t stride_y, int64_t stride_z)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->has_terrain) return fail(ctx, VTMC_ERR_NO_RESULT, "terrain_read_samples before terrain_init");
+    if (!dst) return fail(ctx, VTMC_ERR_INVALID_ARG, "dst is null");
+    if (stride_x <= 0 || stride_y <= 0 || stride_z <= 0) return fail(ctx, VTMC_ERR_INVALID_ARG, "strides must be positive");
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    const TerrainShape &sh = ctx->tshape;
+    const size_t n = (size_t)sh.dim_x * sh.dim_y * sh.dim_z;
+    VTMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (stride_x == 1 && stride_y == sh.dim_x && stride_z == (int64_t)sh.dim_x * sh.dim_y) {
+        VTMC_HIP(ctx, hipMemcpy(dst, ctx->terrain.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        return VTMC_OK;
+    }
+    std::vector<float> tmp(n);
+    VTMC_HIP(ctx, hipMemcpy(tmp.data(), ctx->terrain.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    size_t i = 0;
+    for (int z = 0; z < sh.dim_z; ++z)
+        for (int y = 0; y < sh.dim_y; ++y)
+            for (int x = 0; x < sh.dim_x; ++x) dst[x * stride_x + y * stride_y + z * stride_z] = tmp[i++];
+    return VTMC_OK;
+}
+
+int32_t vtmc_terrain_device_grid(vtmc_ctx *ctx, const float **d_samples, int64_t strides[3], int32_t dims[3])
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->has_terrain) return fail(ctx, VTMC_ERR_NO_RESULT, "terrain_device_grid before terrain_init");
+    const TerrainShape &sh = ctx->tshape;
+    if (d_samples) *d_samples = (const float *)ctx->terrain.p;
+    if (strides) {
+        strides[0] = 1;
+        strides[1] = sh.dim_x;
+        strides[2] = (int64_t)sh.dim_x * sh.dim_y;
+    }
+    if (dims) {
+        dims[0] = sh.dim_x;
+        dims[1] = sh.dim_y;
+        dims[2] = sh.dim_z;
+    }
     return VTMC_OK;
 }
 

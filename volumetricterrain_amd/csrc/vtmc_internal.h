@@ -96,6 +96,23 @@ hipError_t launch_sweep(const BlockSpace &sp, const DeviceTables &tb, void *scra
                         unsigned long long capacity, void *triangles, int n_cus, int n_volumes,
                         uint32_t *volume_counts, const Tuning &tune, hipStream_t stream);
 
+// terrain.hip: device-resident density grid with the reference's CSG write semantics.
+struct TerrainShape {
+    int dim_x, dim_y, dim_z;  // samples per axis = cells + 2 (VoxelTerrain.cs:145); x fastest in memory
+    float scale;              // _voxelScale
+    float origin[3];          // TerrainOrigin
+    uint64_t seed;
+};
+struct TerrainModifierArgs {
+    int kind, add_or_erode;  // vtmc_modifier.kind / .add_or_erode
+    float p[8];              // vtmc_modifier.p
+    int lx, ly, lz;          // first sample of the clamped AABB (VoxelTerrain.cs:273-276)
+    int dx, dy, dz;          // samples per axis of the AABB, inclusive ends (VoxelTerrain.cs:284-286)
+    uint32_t event;          // 1-based index of this modifier application since Init (hash input)
+};
+hipError_t launch_terrain_fill(float *grid, long long n, uint64_t seed, int n_cus, hipStream_t stream);
+hipError_t launch_terrain_modify(float *grid, const TerrainShape &sh, const TerrainModifierArgs &m, hipStream_t stream);
+
 // density.hip
 struct DensityLaunch {
     float frequency, lacunarity, gain, ramp_scale, ramp_center;

@@ -10,7 +10,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import TRI_DTYPE, DensityParams, VolumeBatch, VtmcError
+from ._lib import TRI_DTYPE, DensityParams, Modifier, VolumeBatch, VtmcError
 
 
 def _ptr(a):
@@ -143,6 +143,44 @@ class Extractor:
     def set_tuning(self, **kv):
         for k, v in kv.items():
             self._check(self._L.vtmc_set_tuning(self._h, k.encode(), int(v)))
+
+    # -- device-resident terrain: VoxelTerrain.Init / Update on the GPU ------------------------
+    def terrain_init(self, width, elevation, height, voxel_scale=1.0, origin=(0.0, 0.0, 0.0), seed=1):
+        """VoxelTerrain.Init's grid (VoxelTerrain.cs:121-149) in HBM."""
+        o = (ctypes.c_float * 3)(*origin)
+        self._check(self._L.vtmc_terrain_init(self._h, width, elevation, height, voxel_scale, ctypes.byref(o), seed))
+        self._terrain_dims = (width, elevation, height)
+
+    def terrain_update(self, mods):
+        """VoxelTerrain.Update (VoxelTerrain.cs:262-325) for a queue of Modifier structs.
+        Returns (number of dirty blocks, T)."""
+        mods = [m.to_struct() if hasattr(m, "to_struct") else m for m in mods]
+        arr = (Modifier * max(len(mods), 1))()
+        for i, m in enumerate(mods):
+            ctypes.memmove(ctypes.byref(arr[i]), ctypes.byref(m), ctypes.sizeof(Modifier))
+        nd, t = ctypes.c_int32(), ctypes.c_int32()
+        self._check(self._L.vtmc_terrain_update(self._h, ctypes.cast(arr, ctypes.c_void_p), len(mods),
+                                                ctypes.byref(nd), ctypes.byref(t)))
+        return nd.value, t.value
+
+    def terrain_dirty_blocks(self):
+        n = ctypes.c_int32()
+        self._check(self._L.vtmc_terrain_dirty_blocks(self._h, None, 0, ctypes.byref(n)))
+        out = np.zeros((n.value, 3), np.int32)
+        self._check(self._L.vtmc_terrain_dirty_blocks(self._h, _ptr(out), n.value, ctypes.byref(n)))
+        return out
+
+    def terrain_read_samples(self, order="x"):
+        """The density grid indexed [x, y, z]; order='x': x fastest in memory, 'z': a C# float[,,]."""
+        w, e, h = self._terrain_dims
+        if order == "x":
+            mem = np.empty((h + 2, e + 2, w + 2), np.float32)
+            grid = mem.transpose(2, 1, 0)
+        else:
+            grid = np.empty((w + 2, e + 2, h + 2), np.float32)
+        sx, sy, sz = elem_strides(grid)
+        self._check(self._L.vtmc_terrain_read_samples(self._h, _ptr(grid), sx, sy, sz))
+        return grid
 
     def density_fill_device(self, params, origins, dims, strides, volume_stride, d_out, stream=None):
         origins = np.ascontiguousarray(origins, np.int32).reshape(-1, 3)
