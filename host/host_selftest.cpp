@@ -2,6 +2,7 @@
 // the C# class (TerrainEngine.cs:87,148,160; SceneManager.cs:121-129).
 //   host_selftest --cpu            host logic only (recording backend, no GPU needed)
 //   host_selftest --gpu <out_dir>  real libvtmc.so backend; dumps grid + meshes for the parity test
+//   host_selftest --gpu-resident <out_dir>  the same scene, grid in HBM, Update on the device
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -134,6 +135,48 @@ static int gpu_run(const std::string &out)
     return 0;
 }
 
+// the same scene with the grid resident in HBM and Update's density write on the GPU
+static int gpu_resident_run(const std::string &out)
+{
+    VoxelTerrain vt;
+    vt._width = 64;
+    vt._elevation = 32;
+    vt._height = 64;
+    vt._voxelScale = 0.5f;
+    vt.TerrainOrigin = Vector3(-3.0f, 1.0f, 2.0f);
+    vt._deviceResident = true;
+    vt._seed = 4242;
+    vt.Init();
+    Vector2 lo, up;
+    lo.x = -100; lo.y = -100; up.x = 100; up.y = 100;
+    vt.InsertModifier(std::make_shared<PlaneModifier>(6.3f, lo, up, true));
+    vt.InsertModifier(std::make_shared<SphereModifier>(Vector3(10.0f, 8.0f, 15.0f), 5.5f, true));
+    vt.InsertModifier(std::make_shared<CylinderModifier>(Vector3(2.0f, 5.0f, 6.0f), Vector3(1.0f, 0.3f, 0.5f), 20.0f, 2.2f, false));
+    vt.Update();
+    std::printf("resident: blocks %zu triangles %d\n", vt.LastUpdateBlocks().size(), vt.LastTriangleCount());
+    vt.InsertModifier(std::make_shared<SphereModifier>(Vector3(5.0f, 4.0f, 9.0f), 2.0f, false));
+    vt.Update();
+    std::printf("resident edit: blocks %zu triangles %d\n", vt.LastUpdateBlocks().size(), vt.LastTriangleCount());
+    const std::vector<float> grid = vt.DeviceSamples();
+    std::ofstream(out + "/r_grid.f32", std::ios::binary).write(reinterpret_cast<const char *>(grid.data()), (std::streamsize)(grid.size() * sizeof(float)));
+    std::ofstream fb(out + "/r_blocks.i32", std::ios::binary), fv(out + "/r_vertices.f32", std::ios::binary),
+        fn(out + "/r_normals.f32", std::ios::binary), fc(out + "/r_counts.i32", std::ios::binary);
+    for (const Int3 &b : vt.LastUpdateBlocks()) {
+        int xyz[3] = {b._x, b._y, b._z};
+        fb.write(reinterpret_cast<const char *>(xyz), sizeof xyz);
+        const BlockMesh &m = vt.Block(b._x, b._y, b._z);
+        int n = (int)m.vertices.size();
+        fc.write(reinterpret_cast<const char *>(&n), sizeof n);
+        for (int i = 0; i < n; i++) {
+            fv.write(reinterpret_cast<const char *>(&m.vertices[(size_t)i]), 12);
+            fn.write(reinterpret_cast<const char *>(&m.normals[(size_t)i]), 12);
+        }
+    }
+    vt.Free();
+    std::printf("HOST-RESIDENT-OK\n");
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     try {
@@ -143,6 +186,7 @@ int main(int argc, char **argv)
             return rc;
         }
         if (argc >= 3 && std::string(argv[1]) == "--gpu") return gpu_run(argv[2]);
+        if (argc >= 3 && std::string(argv[1]) == "--gpu-resident") return gpu_resident_run(argv[2]);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "exception: %s\n", e.what());
         return 3;

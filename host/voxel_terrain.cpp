@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <unordered_set>
 
 #include "../include/vtmc.h"
@@ -106,8 +107,54 @@ public:
         if (rc != VTMC_OK) throw UnityException(std::string("vtmc_read_triangles: ") + vtmc_last_error(_ctx));
     }
 
+    bool TerrainInit(int w, int e, int h, float scale, const Vector3 &origin, uint64_t seed) override
+    {
+        const float o[3] = {origin.x, origin.y, origin.z};
+        if (vtmc_terrain_init(_ctx, w, e, h, scale, o, seed) != VTMC_OK)
+            throw UnityException(std::string("vtmc_terrain_init: ") + vtmc_last_error(_ctx));
+        _dims[0] = w;
+        _dims[1] = e;
+        _dims[2] = h;
+        return true;
+    }
+    void TerrainUpdate(const std::vector<QueuedModifier> &queue, std::vector<Int3> &blocks, std::vector<CSTriangle> &tris,
+                       std::vector<int> &offsets) override
+    {
+        std::vector<vtmc_modifier> mods(queue.size());
+        for (size_t i = 0; i < queue.size(); i++) {
+            vtmc_modifier &m = mods[i];
+            m.kind = queue[i].desc.kind;
+            m.add_or_erode = queue[i].addOrErode ? 1 : 0;
+            const Vector3 &lo = queue[i].lower, &up = queue[i].upper;
+            m.lower[0] = lo.x, m.lower[1] = lo.y, m.lower[2] = lo.z;
+            m.upper[0] = up.x, m.upper[1] = up.y, m.upper[2] = up.z;
+            std::memcpy(m.p, queue[i].desc.p, sizeof m.p);
+        }
+        int32_t nDirty = 0, triNum = 0;
+        if (vtmc_terrain_update(_ctx, mods.data(), (int32_t)mods.size(), &nDirty, &triNum) != VTMC_OK)
+            throw UnityException(std::string("vtmc_terrain_update: ") + vtmc_last_error(_ctx));
+        std::vector<int32_t> list((size_t)nDirty * 3);
+        if (vtmc_terrain_dirty_blocks(_ctx, list.data(), nDirty, nullptr) != VTMC_OK)
+            throw UnityException(std::string("vtmc_terrain_dirty_blocks: ") + vtmc_last_error(_ctx));
+        blocks.clear();
+        for (int32_t i = 0; i < nDirty; i++) blocks.emplace_back(list[3 * (size_t)i], list[3 * (size_t)i + 1], list[3 * (size_t)i + 2]);
+        tris.resize((size_t)triNum);
+        offsets.assign((size_t)nDirty + 1, 0);
+        if (nDirty > 0 && vtmc_read_triangles(_ctx, reinterpret_cast<vtmc_triangle *>(tris.data()), triNum, offsets.data()) != VTMC_OK)
+            throw UnityException(std::string("vtmc_read_triangles: ") + vtmc_last_error(_ctx));
+    }
+    void TerrainReadSamples(std::vector<float> &out) override
+    {
+        const int64_t ey = _dims[1] + 2, ez = _dims[2] + 2;
+        out.resize((size_t)(_dims[0] + 2) * ey * ez);
+        // into the C# float[W+2,E+2,H+2] layout: z fastest
+        if (vtmc_terrain_read_samples(_ctx, out.data(), ey * ez, ez, 1) != VTMC_OK)
+            throw UnityException(std::string("vtmc_terrain_read_samples: ") + vtmc_last_error(_ctx));
+    }
+
 private:
     vtmc_ctx *_ctx = nullptr;
+    int _dims[3] = {0, 0, 0};
 };
 }  // namespace
 
@@ -128,9 +175,15 @@ void VoxelTerrain::Init()
 
     _blocks.assign((size_t)(_width / blockSize) * (_elevation / blockSize) * (_height / blockSize), BlockMesh());
     // augmented by one layer so normals on the positive boundary are defined (VoxelTerrain.cs:145)
-    _voxelSamples.resize((size_t)(_width + 2) * (_elevation + 2) * (_height + 2));
-    for (float &s : _voxelSamples) s = voidDensity();
     if (!_backend) _backend = MakeVtmcBackend(_device);  // throws when no HIP device: there is no CPU path
+    if (_deviceResident) {
+        _voxelSamples.clear();  // the grid lives in HBM
+        if (!_backend->TerrainInit(_width, _elevation, _height, _voxelScale, TerrainOrigin, _seed))
+            throw UnityException("backend has no device-resident terrain");
+    } else {
+        _voxelSamples.resize((size_t)(_width + 2) * (_elevation + 2) * (_height + 2));
+        for (float &s : _voxelSamples) s = voidDensity();
+    }
     _nextUpdateblocks.clear();
     _modifierQueue.clear();
     _initialised = true;
@@ -152,6 +205,31 @@ void VoxelTerrain::InsertModifier(std::shared_ptr<TerrainModifier> modifier) { _
 void VoxelTerrain::Update()
 {
     if (!_initialised) throw UnityException("VoxelTerrain.Update before Init");
+    if (_deviceResident) {
+        // the whole of Update on the device: density writes, dirty set, BatchUpdate (VoxelTerrain.cs:262-325)
+        std::vector<ExtractBackend::QueuedModifier> queue;
+        while (!_modifierQueue.empty()) {
+            std::shared_ptr<TerrainModifier> modifier = _modifierQueue.front();
+            _modifierQueue.pop_front();
+            ExtractBackend::QueuedModifier q;
+            if (!modifier->Describe(q.desc)) throw UnityException("modifier cannot be evaluated on the device (Describe() returned false)");
+            q.addOrErode = modifier->AddOrErode;
+            q.lower = modifier->LowerBound();
+            q.upper = modifier->UpperBound();
+            queue.push_back(q);
+        }
+        _lastUpdateBlocks.clear();
+        _lastTriNum = 0;
+        if (queue.empty()) return;
+        std::vector<CSTriangle> csTriangles;
+        std::vector<int> offsets;
+        _backend->TerrainUpdate(queue, _nextUpdateblocks, csTriangles, offsets);
+        _lastUpdateBlocks = _nextUpdateblocks;
+        _lastTriNum = (int)csTriangles.size();
+        if (!csTriangles.empty()) ApplyMeshes(csTriangles, offsets);
+        _nextUpdateblocks.clear();
+        return;
+    }
     struct Hash {
         size_t operator()(const Int3 &k) const { return (size_t)(unsigned)k.GetHashCode(); }
     };
@@ -218,6 +296,20 @@ void VoxelTerrain::BatchUpdate()
     _backend->Extract(_voxelSamples.data(), _width, _elevation, _height, _nextUpdateblocks, csTriangles, offsets);
     _lastTriNum = (int)csTriangles.size();
     if (csTriangles.empty()) return;  // "no triangles, early exit" keeps the old meshes (VoxelTerrain.cs:396-405)
+    ApplyMeshes(csTriangles, offsets);
+}
+
+std::vector<float> VoxelTerrain::DeviceSamples() const
+{
+    std::vector<float> out;
+    if (!_deviceResident || !_backend) throw UnityException("DeviceSamples needs an initialised device-resident terrain");
+    _backend->TerrainReadSamples(out);
+    return out;
+}
+
+// VoxelTerrain.cs:430-465: per dirty block, vertices (scaled by _voxelScale), normals, trivial indices
+void VoxelTerrain::ApplyMeshes(const std::vector<CSTriangle> &csTriangles, const std::vector<int> &offsets)
+{
     const int nby = _elevation / blockSize, nbz = _height / blockSize;
     for (size_t i = 0; i < _nextUpdateblocks.size(); i++) {
         const Int3 &b = _nextUpdateblocks[i];

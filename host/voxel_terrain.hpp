@@ -66,6 +66,13 @@ public:
     using std::runtime_error::runtime_error;
 };
 
+// What the GPU needs to evaluate a modifier itself (vtmc_modifier of include/vtmc.h, redeclared so
+// this header stays free of the C ABI): kind 0 plane, 1 sphere, 2 cylinder + their parameters.
+struct ModifierDesc {
+    int kind = -1;
+    float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
 // TerrainModifier.cs:19-33
 class TerrainModifier {
 public:
@@ -74,6 +81,9 @@ public:
     virtual Vector3 UpperBound() const = 0;
     virtual float QueryDensity(const Vector3 &pos) const = 0;  // > 0 solid, < 0 air
     bool AddOrErode = true;                                    // true: union, false: difference
+    // New: modifiers the library can evaluate on the device describe themselves; any other
+    // (user-defined QueryDensity) returns false and is applied by the host loop as in the reference.
+    virtual bool Describe(ModifierDesc &) const { return false; }
 };
 
 // TerrainModifier.cs:38-65  f = y0 - y
@@ -85,6 +95,12 @@ public:
     Vector3 LowerBound() const override { return {_low.x, std::numeric_limits<float>::lowest(), _low.y}; }
     Vector3 UpperBound() const override { return {_up.x, _height + 1, _up.y}; }
     float QueryDensity(const Vector3 &pos) const override { return _height - pos.y; }
+    bool Describe(ModifierDesc &d) const override
+    {
+        d.kind = 0;
+        d.p[0] = _height;
+        return true;
+    }
 };
 
 // TerrainModifier.cs:70-91  f = r - |p - c|
@@ -96,6 +112,15 @@ public:
     Vector3 LowerBound() const override { return {_center.x - _radius, _center.y - _radius, _center.z - _radius}; }
     Vector3 UpperBound() const override { return {_center.x + _radius, _center.y + _radius, _center.z + _radius}; }
     float QueryDensity(const Vector3 &pos) const override { return _radius - (pos - _center).magnitude(); }
+    bool Describe(ModifierDesc &d) const override
+    {
+        d.kind = 1;
+        d.p[0] = _center.x;
+        d.p[1] = _center.y;
+        d.p[2] = _center.z;
+        d.p[3] = _radius;
+        return true;
+    }
 };
 
 // TerrainModifier.cs:96-152
@@ -107,6 +132,19 @@ public:
     Vector3 LowerBound() const override;
     Vector3 UpperBound() const override;
     float QueryDensity(const Vector3 &pos) const override;
+    bool Describe(ModifierDesc &d) const override
+    {
+        d.kind = 2;
+        d.p[0] = _axisStart.x;
+        d.p[1] = _axisStart.y;
+        d.p[2] = _axisStart.z;
+        d.p[3] = _axisDir.x;
+        d.p[4] = _axisDir.y;
+        d.p[5] = _axisDir.z;
+        d.p[6] = _axisLength;
+        d.p[7] = _radius;
+        return true;
+    }
 };
 
 // What replaces a block's Unity Mesh (VoxelTerrain.cs:448-465): unindexed soup, indices 0..n-1.
@@ -134,6 +172,22 @@ struct ExtractBackend {
     // order) and blockTriOffsets (B+1).  Throws UnityException on failure.
     virtual void Extract(const float *grid, int width, int elevation, int height, const std::vector<MathHelper::Int3> &blocks,
                          std::vector<CSTriangle> &tris, std::vector<int> &blockTriOffsets) = 0;
+
+    // Device-resident terrain (vtmc_terrain_*): the grid lives in HBM, Update's density write runs on
+    // the GPU.  A backend without it returns false from TerrainInit and the host path is used.
+    struct QueuedModifier {
+        ModifierDesc desc;
+        bool addOrErode;
+        Vector3 lower, upper;  // LowerBound / UpperBound, evaluated on the host as VoxelTerrain.cs:273-279 does
+    };
+    virtual bool TerrainInit(int, int, int, float, const Vector3 &, uint64_t) { return false; }
+    // Applies the queue in order and extracts the dirty set; fills blocks (ordered by block id), tris, offsets.
+    virtual void TerrainUpdate(const std::vector<QueuedModifier> &, std::vector<MathHelper::Int3> &, std::vector<CSTriangle> &,
+                               std::vector<int> &)
+    {
+        throw std::logic_error("TerrainUpdate on a backend without device-resident terrain");
+    }
+    virtual void TerrainReadSamples(std::vector<float> &) { throw std::logic_error("TerrainReadSamples unsupported"); }
 };
 
 class VoxelTerrain {
@@ -146,6 +200,10 @@ public:
     float _voxelScale = 1.0f;                         // VoxelTerrain.cs:107
     Vector3 TerrainOrigin;                            // _transform.position, VoxelTerrain.cs:101
     int _device = 0;                                  // HIP device of the vtmc context (new)
+    // New: keep _voxelSamples in HBM and run Update's density write on the GPU (vtmc_terrain_*).
+    // Queues holding a modifier the device cannot evaluate (Describe() == false) are refused.
+    bool _deviceResident = false;
+    uint64_t _seed = 1;                               // seed of the device-side void / full values
 
     VoxelTerrain();
     ~VoxelTerrain();
@@ -165,12 +223,14 @@ public:
     const BlockMesh &Block(int x, int y, int z) const { return _blocks[((size_t)x * (_elevation / blockSize) + y) * (_height / blockSize) + z]; }
     float Sample(int x, int y, int z) const { return _voxelSamples[((size_t)x * (_elevation + 2) + y) * (_height + 2) + z]; }
     const std::vector<float> &Samples() const { return _voxelSamples; }
+    std::vector<float> DeviceSamples() const;  // device-resident mode: the grid copied back (z fastest, like Samples())
     const std::vector<MathHelper::Int3> &LastUpdateBlocks() const { return _lastUpdateBlocks; }
     int LastTriangleCount() const { return _lastTriNum; }
     void SeedRandom(uint32_t seed) { _rng.seed(seed); }
     void SetBackend(std::shared_ptr<ExtractBackend> backend) { _backend = std::move(backend); }
 
 private:
+    void ApplyMeshes(const std::vector<CSTriangle> &csTriangles, const std::vector<int> &offsets);  // VoxelTerrain.cs:430-465
     std::vector<float> _voxelSamples;  // float[W+2, E+2, H+2], row-major, z fastest (VoxelTerrain.cs:145)
     std::vector<BlockMesh> _blocks;    // GameObject[,,] stand-in (VoxelTerrain.cs:61)
     std::vector<MathHelper::Int3> _nextUpdateblocks, _lastUpdateBlocks;

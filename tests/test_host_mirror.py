@@ -43,3 +43,30 @@ def test_host_mirror_end_to_end(tmp_path, oracle_mod):
     assert np.abs(verts - wv).max() <= 1e-5
     ok = ~np.isnan(wn)
     assert np.array_equal(np.isnan(nrms), ~ok) and np.abs(nrms[ok] - wn[ok]).max() <= 1e-5
+
+
+@pytest.mark.gpu
+def test_host_mirror_device_resident(tmp_path, oracle_mod):
+    """_deviceResident = true: Init / Update run on the GPU (vtmc_terrain_*); the grid read back
+    equals the oracle's Update bit for bit, the meshes of the last Update match the oracle's
+    extraction of that grid."""
+    exe = build_host()
+    r = subprocess.run([exe, "--gpu-resident", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "HOST-RESIDENT-OK" in r.stdout, r.stdout + r.stderr
+    W, E, H, scale, origin = 64, 32, 64, 0.5, (-3.0, 1.0, 2.0)
+    ref = oracle_mod.Terrain(W, E, H, scale, origin, seed=4242)
+    ref.update([oracle_mod.plane_modifier(6.3, (-100, -100), (100, 100)),
+                oracle_mod.sphere_modifier((10.0, 8.0, 15.0), 5.5),
+                oracle_mod.cylinder_modifier((2.0, 5.0, 6.0), (1.0, 0.3, 0.5), 20.0, 2.2, add=False)])
+    dirty = ref.update([oracle_mod.sphere_modifier((5.0, 4.0, 9.0), 2.0, add=False)])
+    grid = np.fromfile(tmp_path / "r_grid.f32", np.float32).reshape(W + 2, E + 2, H + 2)
+    assert np.array_equal(grid, ref.grid)
+    blocks = np.fromfile(tmp_path / "r_blocks.i32", np.int32).reshape(-1, 3)
+    assert np.array_equal(blocks, dirty)
+    counts = np.fromfile(tmp_path / "r_counts.i32", np.int32)
+    verts = np.fromfile(tmp_path / "r_vertices.f32", np.float32).reshape(-1, 3, 3)
+    nrms = np.fromfile(tmp_path / "r_normals.f32", np.float32).reshape(-1, 3, 3)
+    want, offs, _ = oracle_mod.extract_grid(ref.grid, dirty)
+    assert len(want) > 0 and np.array_equal(np.diff(offs) * 3, counts)
+    wv, wn, _ = oracle_mod.bin_triangles(want, len(dirty), voxel_scale=scale)
+    assert np.abs(verts - wv).max() <= 1e-5 and np.abs(nrms - wn).max() <= 1e-5
