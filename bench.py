@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1024, help="cells per axis of one rank's grid")
+    ap.add_argument("--grid", "--n", dest="n", type=int, default=1024, help="cells per axis of one rank's grid")
     ap.add_argument("--chunk", type=int, default=128, help="cells per axis of a chunk")
     ap.add_argument("--kind", default="perlin3d", choices=["perlin3d", "fbm8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -111,9 +111,17 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the extraction path has no CPU fallback")
+    # rehearsal hook for a one-GPU box: every rank on device 0, gloo instead of RCCL (which refuses
+    # two ranks on one device); the driver's multi-GPU runs use neither variable
+    if os.environ.get("VTMC_BENCH_ONE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("VTMC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     n, c = args.n, args.chunk
     dim = c + 2
@@ -148,12 +156,8 @@ def main():
                 stage_acc[k] += v
         if world > 1:
             # the only exchange of the path: all-gather of per-chunk {vertices, triangles}
-            _, _, vc_ptr = ex.device_results()
-            import ctypes
-            ctypes.CDLL("libamdhip64.so").hipMemcpyAsync(
-                ctypes.c_void_p(counts_dev.data_ptr()), ctypes.c_void_p(vc_ptr), ctypes.c_size_t(8 * n_chunks),
-                ctypes.c_int(3), ctypes.c_void_p(stream.cuda_stream))
-            gathered = sharding.allgather_counts(counts_dev)
+            ex.copy_volume_counts_device(counts_dev.data_ptr(), n_chunks, stream.cuda_stream)
+            gathered = sharding.allgather_counts(counts_dev if backend == "nccl" else counts_dev.cpu())
             offs = torch.cumsum(gathered.transpose(0, 1).reshape(-1, 2).to(torch.int64), 0)  # global chunk order
             return T, offs
         return T, None
@@ -171,11 +175,11 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed, float(T)], dtype=torch.float64, device="cuda")
-        el = tmax.clone()
+        red_dev = "cuda" if backend == "nccl" else "cpu"
+        el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el[0])
-        tsum = torch.tensor([float(T)], dtype=torch.float64, device="cuda")
+        tsum = torch.tensor([float(T)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         total_tris = float(tsum[0])
     else:
@@ -207,7 +211,7 @@ def main():
         ach = alg[dom] / (avg[dom] * 1e-3) / 1e9
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_file):
+        if os.path.exists(pmc_file) and n == 1024 and c == 128 and args.kind == "perlin3d":  # the PMC passes were taken on this workload
             try:
                 traffic = json.load(open(pmc_file)).get(dom + "_kernel_hbm_bytes")
             except Exception:
@@ -227,7 +231,7 @@ def main():
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(d_field, dim, c, min(args.cpu_sample_chunks, n_chunks), args.kind)
         out = {
-            "metric": "marching-cubes extraction throughput on a 1024^3 perlin3d grid (Mvoxels/s)",
+            "metric": "marching-cubes extraction throughput on a %d^3 %s grid per GPU (Mvoxels/s)" % (n, args.kind),
             "value": round(value, 1),
             "unit": "Mvoxels/s",
             "n_gpus": world,

@@ -135,6 +135,11 @@ int32_t vtmc_extract_volumes_device(vtmc_ctx *ctx, const vtmc_volume_batch *batc
 int32_t vtmc_device_results(vtmc_ctx *ctx, const vtmc_triangle **d_triangles,
                             const uint32_t **d_block_tri_offsets, const uint32_t **d_volume_counts);
 
+/* Copies volume_counts of the last extract_* (n_volumes x {vertices, triangles} u32) into a
+ * caller-owned DEVICE buffer on `stream` (NULL = the context's stream), asynchronously: the buffer a
+ * multi-GPU caller hands to its all-gather (RCCL), SURVEY.md 8e. */
+int32_t vtmc_copy_volume_counts_device(vtmc_ctx *ctx, uint32_t *d_dst, int32_t capacity_volumes, void *stream);
+
 /* Pre-size the triangle buffer (otherwise it grows on demand and the emit stage is re-run once). */
 int32_t vtmc_reserve_triangles(vtmc_ctx *ctx, int64_t capacity);
 

@@ -28,7 +28,7 @@ SYMBOLS = [
     "vtmc_last_counts", "vtmc_extract_volumes_device", "vtmc_device_results",
     "vtmc_reserve_triangles", "vtmc_last_stage_ms", "vtmc_set_tuning", "vtmc_density_fill_device",
     "vtmc_terrain_init", "vtmc_terrain_update", "vtmc_terrain_dirty_blocks", "vtmc_terrain_read_samples",
-    "vtmc_terrain_device_grid",
+    "vtmc_terrain_device_grid", "vtmc_copy_volume_counts_device",
 ]
 
 MOD_PLANE, MOD_SPHERE, MOD_CYLINDER = 0, 1, 2
@@ -95,6 +95,7 @@ def load():
     L.vtmc_extract_volumes_device.argtypes = [vp, P(VolumeBatch), vp, u32, P(i64)]
     L.vtmc_device_results.argtypes = [vp, P(vp), P(vp), P(vp)]
     L.vtmc_reserve_triangles.argtypes = [vp, i64]
+    L.vtmc_copy_volume_counts_device.argtypes = [vp, vp, i32, vp]
     L.vtmc_last_stage_ms.argtypes = [vp, P(ctypes.c_float * 4)]
     L.vtmc_set_tuning.argtypes = [vp, ctypes.c_char_p, i32]
     L.vtmc_density_fill_device.argtypes = [vp, P(DensityParams), vp, i32, i32, i32, i32,

@@ -530,6 +530,19 @@ int32_t vtmc_device_results(vtmc_ctx *ctx, const vtmc_triangle **d_triangles, co
     return VTMC_OK;
 }
 
+int32_t vtmc_copy_volume_counts_device(vtmc_ctx *ctx, uint32_t *d_dst, int32_t capacity_volumes, void *stream)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->has_result) return fail(ctx, VTMC_ERR_NO_RESULT, "copy_volume_counts before any extract");
+    if (capacity_volumes < ctx->last_volumes) return fail(ctx, VTMC_ERR_CAPACITY, "capacity %d < %d volumes", capacity_volumes, ctx->last_volumes);
+    if (ctx->last_volumes == 0 || ctx->last_blocks == 0) return VTMC_OK;
+    if (!d_dst) return fail(ctx, VTMC_ERR_INVALID_ARG, "d_dst is null");
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    VTMC_HIP(ctx, hipMemcpyAsync(d_dst, ctx->volcounts.p, sizeof(uint32_t) * 2 * (size_t)ctx->last_volumes, hipMemcpyDeviceToDevice,
+                                 stream ? (hipStream_t)stream : ctx->stream));
+    return VTMC_OK;
+}
+
 int32_t vtmc_reserve_triangles(vtmc_ctx *ctx, int64_t capacity)
 {
     if (!ctx) return VTMC_ERR_INVALID_ARG;

@@ -132,6 +132,11 @@ class Extractor:
         self._check(self._L.vtmc_device_results(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return a.value, b.value, c.value
 
+    def copy_volume_counts_device(self, d_dst, capacity_volumes, stream=None):
+        """Per-volume {vertices, triangles} of the last extract into a caller-owned device buffer
+        (async on `stream`): what the multi-GPU driver all-gathers."""
+        self._check(self._L.vtmc_copy_volume_counts_device(self._h, d_dst, capacity_volumes, stream))
+
     def reserve_triangles(self, capacity):
         self._check(self._L.vtmc_reserve_triangles(self._h, int(capacity)))
 
