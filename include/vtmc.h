@@ -226,6 +226,16 @@ int32_t vtmc_terrain_read_samples(vtmc_ctx *ctx, float *dst, int64_t stride_x, i
 /* Device pointer + element strides of the grid (x fastest), for GPU-resident callers. */
 int32_t vtmc_terrain_device_grid(vtmc_ctx *ctx, const float **d_samples, int64_t strides[3], int32_t dims[3]);
 
+/* The same fill without the final synchronisation: queued on `stream` (NULL = the context's stream)
+ * and ordered only by it, so a streaming driver can generate batch k+1 on one context / stream while
+ * batch k is extracted on another (BASELINE config "2048^3 streaming grid, double-buffered chunks").
+ * The origins are staged in context-owned device memory: issue fills of ONE context on one stream. */
+int32_t vtmc_density_fill_device_async(vtmc_ctx *ctx, const vtmc_density_params *params,
+                                       const int32_t *origins, int32_t n_volumes,
+                                       int32_t dim_x, int32_t dim_y, int32_t dim_z,
+                                       int64_t stride_x, int64_t stride_y, int64_t stride_z,
+                                       int64_t volume_stride, float *d_out, void *stream);
+
 /* Library / build identification: "vtmc <version> gfx950". */
 const char *vtmc_version(void);
 

@@ -289,3 +289,89 @@ def test_config_1024_chunked_properties(ex, oracle_mod):
         want["block"] += v * bpv
         assert_tris_match(got, want)
         assert np.array_equal(offs[v * bpv:(v + 1) * bpv + 1].astype(np.int64) - int(offs[v * bpv]), want_offs)
+
+
+def test_config_streaming_fbm8_double_buffered(ex, oracle_mod):
+    """BASELINE config[4] at test scale: an fbm8 world streamed as double-buffered batches of 128^3
+    chunks (batch k+1 sampled while batch k is extracted).  The stream's per-chunk counts equal a
+    one-shot extraction of the same chunks, and one chunk of a late batch matches the oracle on the
+    device-generated samples."""
+    import torch
+    import volumetricterrain_amd as vt
+    from volumetricterrain_amd import sharding
+    from volumetricterrain_amd.streaming import ChunkStream
+    world, c = (256, 256, 384), 128
+    dim = c + 2
+    with ChunkStream(world, chunk=c, batch_chunks=5, kind="fbm8", noise_n=256) as st:   # ramp centre y = 128; 12 chunks -> batches of 5, 5, 2
+        assert st.n_batches() == 3
+        kept = None
+        total, counts = 0, []
+        for k, org, T, bex in st.batches():
+            tri_ptr, off_ptr, vc_ptr = bex.device_results()
+            vc = sharding.copy_device_u32(vc_ptr, 2 * len(org)).reshape(-1, 2)
+            counts.append(vc)
+            total += T
+            if k == 2:   # keep the last chunk of the last batch for the oracle
+                offs = sharding.copy_device_u32(off_ptr, len(org) * st.bpv + 1)
+                lo, hi = int(offs[(len(org) - 1) * st.bpv]), int(offs[len(org) * st.bpv])
+                kept = (org[-1].copy(), sharding.copy_device_bytes(tri_ptr + 76 * lo, 76 * (hi - lo)).view(vt.TRI_DTYPE).copy())
+        counts = np.concatenate(counts)
+        all_origins = st.origins.copy()
+        prm = st.params
+    assert counts[:, 1].sum() == total and total > 0
+    # one-shot: all 12 chunks generated and extracted in a single batch
+    d = torch.empty(len(all_origins) * dim ** 3, dtype=torch.float32, device="cuda")
+    ex.density_fill_device(prm, all_origins, (dim, dim, dim), (1, dim, dim * dim), dim ** 3, d.data_ptr())
+    T1 = ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), len(all_origins), dim ** 3)
+    _, _, vc_ptr = ex.device_results()
+    vc1 = sharding.copy_device_u32(vc_ptr, 2 * len(all_origins)).reshape(-1, 2)
+    assert T1 == total and np.array_equal(vc1, counts)
+    # the kept chunk against the oracle, fed the device-generated samples
+    v = len(all_origins) - 1
+    assert np.array_equal(all_origins[v], kept[0])
+    sub = d[v * dim ** 3:(v + 1) * dim ** 3].cpu().numpy().reshape(dim, dim, dim).transpose(2, 1, 0)
+    want, _, _ = oracle_mod.extract_grid(sub, threads=oracle_mod.max_threads())
+    got = kept[1].copy()
+    got["block"] %= st.bpv          # batch-local block id = chunk-in-batch * bpv + block
+    assert_tris_match(got, want)
+
+
+def test_max_size_single_grid_equals_chunked(ex, oracle_mod):
+    """The largest world the reference accepts (1025 samples per axis, VoxelTerrain.cs:44, plus the
+    halo layer) as ONE 1026^3 volume against the same field cut into 512 chunks of 130^3:
+    block-decomposition invariance at full size.  Per-chunk triangle counts and
+    an order-independent checksum of every record's floats agree; block ids differ by construction."""
+    import torch
+    import volumetricterrain_amd as vt
+    from volumetricterrain_amd import sharding
+    n, c = 1024, 128
+    prm = vt.density_params("perlin3d", n)
+    dim = n + 2
+    whole = torch.empty(dim ** 3, dtype=torch.float32, device="cuda")
+    ex.density_fill_device(prm, [[0, 0, 0]], (dim, dim, dim), (1, dim, dim * dim), 0, whole.data_ptr())
+    T = ex.extract_volumes_device(whole.data_ptr(), (n, n, n), (1, dim, dim * dim), 1, 0)
+    tri_ptr, off_ptr, _ = ex.device_results()
+    nb = n // 8
+    counts = np.diff(sharding.copy_device_u32(off_ptr, nb ** 3 + 1).astype(np.int64)).reshape(nb, nb, nb)   # [bz, by, bx]
+    k = c // 8
+    per_chunk_whole = counts.reshape(nb // k, k, nb // k, k, nb // k, k).sum(axis=(1, 3, 5)).reshape(-1)     # chunk = cx + ncx*(cy + ncy*cz)
+
+    def float_checksum(ptr, count):
+        t = torch.empty(count * 19, dtype=torch.int32, device="cuda")
+        sharding._hiprt().hipMemcpy(t.data_ptr(), ptr, 76 * count, 3)   # device -> device
+        words = t.view(-1, 19)[:, :18].to(torch.int64) & 0xFFFFFFFF
+        w = words % 1000003
+        return int(words.sum().item()), int((w * w % 1000003).sum().item())
+
+    sum_whole = float_checksum(tri_ptr, T)
+    del whole
+    cdim = c + 2
+    origins = sharding.chunk_origins(n, c)
+    d = torch.empty(len(origins) * cdim ** 3, dtype=torch.float32, device="cuda")
+    ex.density_fill_device(prm, origins, (cdim, cdim, cdim), (1, cdim, cdim * cdim), cdim ** 3, d.data_ptr())
+    T2 = ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, cdim, cdim * cdim), len(origins), cdim ** 3)
+    tri_ptr, _, vc_ptr = ex.device_results()
+    vc = sharding.copy_device_u32(vc_ptr, 2 * len(origins)).reshape(-1, 2)
+    assert T2 == T == 42485756
+    assert np.array_equal(vc[:, 1].astype(np.int64), per_chunk_whole)
+    assert float_checksum(tri_ptr, T2) == sum_whole

@@ -28,7 +28,7 @@ SYMBOLS = [
     "vtmc_last_counts", "vtmc_extract_volumes_device", "vtmc_device_results",
     "vtmc_reserve_triangles", "vtmc_last_stage_ms", "vtmc_set_tuning", "vtmc_density_fill_device",
     "vtmc_terrain_init", "vtmc_terrain_update", "vtmc_terrain_dirty_blocks", "vtmc_terrain_read_samples",
-    "vtmc_terrain_device_grid", "vtmc_copy_volume_counts_device",
+    "vtmc_terrain_device_grid", "vtmc_copy_volume_counts_device", "vtmc_density_fill_device_async",
 ]
 
 MOD_PLANE, MOD_SPHERE, MOD_CYLINDER = 0, 1, 2
@@ -100,6 +100,7 @@ def load():
     L.vtmc_set_tuning.argtypes = [vp, ctypes.c_char_p, i32]
     L.vtmc_density_fill_device.argtypes = [vp, P(DensityParams), vp, i32, i32, i32, i32,
                                            i64, i64, i64, i64, vp, vp]
+    L.vtmc_density_fill_device_async.argtypes = L.vtmc_density_fill_device.argtypes
     L.vtmc_terrain_init.argtypes = [vp, i32, i32, i32, ctypes.c_float, P(ctypes.c_float * 3), ctypes.c_uint64]
     L.vtmc_terrain_update.argtypes = [vp, vp, i32, P(i32), P(i32)]
     L.vtmc_terrain_dirty_blocks.argtypes = [vp, vp, i32, P(i32)]

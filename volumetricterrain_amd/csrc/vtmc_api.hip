@@ -45,7 +45,7 @@ struct vtmc_ctx {
     DevBuf d_vert, d_trinum;
     DevBuf counts, offsets, active, partials, totals, volcounts, cases, tris, input, list, perm, origins, sweep;
     uint32_t *h_totals = nullptr;  // pinned: {T, nActive} of the scan, or the sweep kernel's kCtrlWords control words
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0..3] stage timing, [4] staging copies
     float stage_ms[4] = {0, 0, 0, 0};
     // last result
     bool has_result = false;
@@ -758,7 +758,7 @@ int32_t vtmc_terrain_device_grid(vtmc_ctx *ctx, const float **d_samples, int64_t
     return VTMC_OK;
 }
 
-int32_t vtmc_density_fill_device(vtmc_ctx *ctx, const vtmc_density_params *params, const int32_t *origins, int32_t n_volumes,
+int32_t vtmc_density_fill_device_async(vtmc_ctx *ctx, const vtmc_density_params *params, const int32_t *origins, int32_t n_volumes,
                                  int32_t dim_x, int32_t dim_y, int32_t dim_z, int64_t stride_x, int64_t stride_y,
                                  int64_t stride_z, int64_t volume_stride, float *d_out, void *stream)
 {
@@ -772,12 +772,18 @@ int32_t vtmc_density_fill_device(vtmc_ctx *ctx, const vtmc_density_params *param
         unsigned char perm[256];
         density_permutation(params->seed, perm);
         if (int rc = ensure(ctx, ctx->perm, 256)) return rc;
+        VTMC_HIP(ctx, hipStreamSynchronize(st));  // nothing queued may still read the old table
         VTMC_HIP(ctx, hipMemcpy(ctx->perm.p, perm, 256, hipMemcpyHostToDevice));
         ctx->perm_seed = params->seed;
         ctx->perm_valid = true;
     }
+    if (ctx->origins.bytes < sizeof(int32_t) * 3 * (size_t)n_volumes) VTMC_HIP(ctx, hipStreamSynchronize(st));  // about to reallocate
     if (int rc = ensure(ctx, ctx->origins, sizeof(int32_t) * 3 * (size_t)n_volumes)) return rc;
-    VTMC_HIP(ctx, hipMemcpy(ctx->origins.p, origins, sizeof(int32_t) * 3 * (size_t)n_volumes, hipMemcpyHostToDevice));
+    // stream-ordered behind any earlier fill of this context that still reads the previous origins
+    VTMC_HIP(ctx, hipMemcpyAsync(ctx->origins.p, origins, sizeof(int32_t) * 3 * (size_t)n_volumes, hipMemcpyHostToDevice, st));
+    // the caller's array is only borrowed for this call: wait for that small copy (and for nothing queued after it)
+    VTMC_HIP(ctx, hipEventRecord(ctx->ev[4], st));
+    VTMC_HIP(ctx, hipEventSynchronize(ctx->ev[4]));
     DensityLaunch dl{};
     dl.frequency = params->frequency;
     dl.lacunarity = params->lacunarity;
@@ -794,7 +800,17 @@ int32_t vtmc_density_fill_device(vtmc_ctx *ctx, const vtmc_density_params *param
     dl.sv = volume_stride;
     dl.n_volumes = n_volumes;
     VTMC_HIP(ctx, launch_density(dl, (const unsigned char *)ctx->perm.p, (const int *)ctx->origins.p, d_out, st));
-    VTMC_HIP(ctx, hipStreamSynchronize(st));
+    return VTMC_OK;
+}
+
+int32_t vtmc_density_fill_device(vtmc_ctx *ctx, const vtmc_density_params *params, const int32_t *origins, int32_t n_volumes,
+                                 int32_t dim_x, int32_t dim_y, int32_t dim_z, int64_t stride_x, int64_t stride_y,
+                                 int64_t stride_z, int64_t volume_stride, float *d_out, void *stream)
+{
+    if (int32_t rc = vtmc_density_fill_device_async(ctx, params, origins, n_volumes, dim_x, dim_y, dim_z, stride_x, stride_y, stride_z,
+                                                    volume_stride, d_out, stream))
+        return rc;
+    VTMC_HIP(ctx, hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
     return VTMC_OK;
 }
 

@@ -187,8 +187,10 @@ class Extractor:
         self._check(self._L.vtmc_terrain_read_samples(self._h, _ptr(grid), sx, sy, sz))
         return grid
 
-    def density_fill_device(self, params, origins, dims, strides, volume_stride, d_out, stream=None):
+    def density_fill_device(self, params, origins, dims, strides, volume_stride, d_out, stream=None, wait=True):
+        """wait=False queues the fill on `stream` without synchronising (vtmc_density_fill_device_async)."""
         origins = np.ascontiguousarray(origins, np.int32).reshape(-1, 3)
-        self._check(self._L.vtmc_density_fill_device(self._h, ctypes.byref(params), _ptr(origins), len(origins),
+        fn = self._L.vtmc_density_fill_device if wait else self._L.vtmc_density_fill_device_async
+        self._check(fn(self._h, ctypes.byref(params), _ptr(origins), len(origins),
                                                      dims[0], dims[1], dims[2], strides[0], strides[1],
                                                      strides[2], volume_stride, d_out, stream))
