@@ -175,6 +175,38 @@ int32_t vtmc_density_fill_device(vtmc_ctx *ctx, const vtmc_density_params *param
                                  int64_t volume_stride, float *d_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Indexed (welded) output -- new; the reference welds on the CPU afterwards with Mesh.Optimize()
+ * (VoxelTerrain.cs:460).  Per block: one vertex per lattice edge with a sign change (all cells
+ * around the edge share it), ordered by lattice point x + 9y + 81z then axis; three block-local
+ * int32 indices per triangle in the canonical triangle order.  ~24 bytes per triangle instead of 76.
+ * De-indexing reproduces the 76-byte records within the 1e-5 bar (the reference evaluates an edge
+ * from either end depending on the cell; here always from its low end).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vtmc_vertex {
+    float position[3]; /* block-local, cell units [0,8] */
+    float normal[3];
+} vtmc_vertex;
+
+#define VTMC_OUTPUT_SOUP 0    /* 76-byte CSTriangle records (default) */
+#define VTMC_OUTPUT_INDEXED 1 /* vtmc_vertex + index buffers */
+
+/* Selects what the following extract_* / terrain_update calls produce. */
+int32_t vtmc_set_output_mode(vtmc_ctx *ctx, int32_t mode);
+
+/* Vertex count of the last extract in indexed mode (tri count: vtmc_last_counts). */
+int32_t vtmc_last_vertex_count(const vtmc_ctx *ctx, int32_t *vertex_count);
+
+/* Copies the indexed mesh of the last extract: V vertices, 3*T indices (block-local: add nothing,
+ * a block's vertices are vertices[block_vertex_offsets[b] .. block_vertex_offsets[b+1])), and the
+ * two per-block exclusive prefixes (n_blocks+1 entries each, optional). */
+int32_t vtmc_read_indexed_mesh(vtmc_ctx *ctx, vtmc_vertex *vertices, int64_t vertex_capacity, int32_t *indices,
+                               int64_t tri_capacity, int32_t *block_vertex_offsets, int32_t *block_tri_offsets);
+
+/* Device pointers of the same (valid until the next extract_* / destroy). */
+int32_t vtmc_device_indexed_results(vtmc_ctx *ctx, const vtmc_vertex **d_vertices, const int32_t **d_indices,
+                                    const uint32_t **d_block_vertex_offsets, const uint32_t **d_block_tri_offsets);
+
+/* ------------------------------------------------------------------------------------------
  * Device-resident terrain: the density grid of VoxelTerrain and its Update() on the GPU.
  * Replaces _voxelSamples (VoxelTerrain.cs:42,145), the per-sample CSG loop of Update
  * (VoxelTerrain.cs:284-305), the dirty-block selection (VoxelTerrain.cs:307-317) and the hand-off to

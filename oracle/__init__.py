@@ -63,6 +63,8 @@ def lib():
         L.vto_density_permutation.argtypes = [ctypes.c_uint64, vp]
         L.vto_density_fill.argtypes = [ctypes.POINTER(DensityParams), i32, i32, i32, i32, i32, i32,
                                        i64, i64, i64, vp]
+        L.vto_extract_grid_indexed.argtypes = [vp, i64, i64, i64, vp, i32, vp, i64, vp, i64, vp, vp, vp]
+        L.vto_extract_grid_indexed.restype = i64
         L.vto_terrain_fill.argtypes = [vp, i32, i32, i32, ctypes.c_uint64]
         L.vto_terrain_update.argtypes = [vp, i32, i32, i32, f32, vp, ctypes.c_uint64, ctypes.c_uint32, vp, i32, vp]
         L.vto_terrain_update.restype = i64
@@ -164,6 +166,42 @@ def extract_grid(grid, block_list=None, threads=1, want_cases=False, count_only=
                                  None, threads)
     assert got == total
     return tris, offs, cases
+
+
+VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3)])
+
+
+def extract_grid_indexed(grid, block_list=None):
+    """Welded form (oracle's own rule, see mc_oracle.c): (vertices, indices[T,3], vertex_offsets, tri_offsets)."""
+    nx, ny, nz = (d - 2 for d in grid.shape)
+    if block_list is None:
+        block_list = all_blocks(nx, ny, nz)
+    block_list = np.ascontiguousarray(block_list, np.int32)
+    B = len(block_list)
+    sx, sy, sz = elem_strides(grid)
+    voffs, toffs = np.empty(B + 1, np.int32), np.empty(B + 1, np.int32)
+    nv = ctypes.c_int64()
+    T = lib().vto_extract_grid_indexed(_p(grid), sx, sy, sz, _p(block_list), B, None, 0, None, 0, _p(voffs), _p(toffs),
+                                       ctypes.byref(nv))
+    verts = np.zeros(nv.value, VERTEX_DTYPE)
+    idx = np.zeros((T, 3), np.int32)
+    got = lib().vto_extract_grid_indexed(_p(grid), sx, sy, sz, _p(block_list), B, _p(verts), len(verts), _p(idx), T,
+                                         _p(voffs), _p(toffs), ctypes.byref(nv))
+    assert got == T
+    return verts, idx, voffs, toffs
+
+
+def deindex(verts, idx, voffs, toffs):
+    """Indexed mesh -> 76-byte records in canonical order (block ids from the offsets)."""
+    T = len(idx)
+    out = np.zeros(T, TRI_DTYPE)
+    block = np.repeat(np.arange(len(toffs) - 1, dtype=np.int32), np.diff(toffs))
+    g = idx + voffs[block][:, None]
+    for k in range(3):
+        out["p%d" % k] = verts["position"][g[:, k]]
+        out["n%d" % k] = verts["normal"][g[:, k]]
+    out["block"] = block
+    return out
 
 
 def max_threads():

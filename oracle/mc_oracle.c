@@ -323,3 +323,92 @@ int64_t vto_extract_grid(const float *grid, int64_t sx, int64_t sy, int64_t sz,
     free(own);
     return total;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Indexed (welded) form of the same meshes -- the checker of the HIP library's VTMC_OUTPUT_INDEXED
+ * mode.  The reference has no such format (it welds later with Mesh.Optimize(), VoxelTerrain.cs:460):
+ * the welding RULE below is the build's own, everything it evaluates is the reference's arithmetic.
+ *   vertex  = one per lattice edge of the block's 9^3 lattice whose endpoints differ in sign class
+ *             (CollectTriNum.compute:50, strict '>'), ordered by point x + 9y + 81z, then axis x, y, z;
+ *             position = MarchingCube.compute:128-133 evaluated from the edge's LOW endpoint
+ *             (a = low, b = high: t = -cube[a] / (cube[b] - cube[a]), lerp(a, b, t)), normal =
+ *             SampleNormalTrilinear (MarchingCube.compute:69-99) at that position;
+ *   indices = for every triangle of the canonical order, the block-local ids of the vertices on its
+ *             three edges, with the reference's winding swap (MarchingCube.compute:147-157).
+ * Returns T; *n_vertices receives V.  vertices / indices may be NULL (count only).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    float position[3];
+    float normal[3];
+} vto_vertex;
+
+int64_t vto_extract_grid_indexed(const float *grid, int64_t sx, int64_t sy, int64_t sz, const int32_t *block_list,
+                                 int32_t n_blocks, vto_vertex *vertices, int64_t vertex_capacity, int32_t *indices,
+                                 int64_t tri_capacity, int32_t *block_vertex_offsets, int32_t *block_tri_offsets,
+                                 int64_t *n_vertices)
+{
+    build_tables();
+    int64_t T = 0, V = 0;
+    static const int step[3] = {1, IS, IS2};
+    for (int32_t b = 0; b < n_blocks; ++b) {
+        float tile[IS3];
+        float nrm[SS3 * 3];
+        uint32_t flags[512];
+        int32_t vid[SS3][3];
+        gather_one(grid, sx, sy, sz, block_list + 3 * (int64_t)b, tile);
+        if (block_vertex_offsets) block_vertex_offsets[b] = (int32_t)V;
+        if (block_tri_offsets) block_tri_offsets[b] = (int32_t)T;
+        if (classify_one(tile, flags) == 0) continue;
+        normals_one(tile, nrm);
+        int32_t nv = 0;
+        for (int z = 0; z < SS; ++z)
+            for (int y = 0; y < SS; ++y)
+                for (int x = 0; x < SS; ++x) {
+                    const int c[3] = {x, y, z};
+                    const int p = x + y * SS + z * SS2, ti = x + y * IS + z * IS2;
+                    for (int a = 0; a < 3; ++a) {
+                        vid[p][a] = -1;
+                        if (c[a] >= BS) continue;
+                        const float va = tile[ti], vb = tile[ti + step[a]];
+                        if ((va > 0) == (vb > 0)) continue;
+                        vid[p][a] = nv;
+                        if (vertices) {
+                            if (V + nv >= vertex_capacity) return -1;
+                            vto_vertex *o = vertices + V + nv;
+                            const float t = (-va) / (vb - va);
+                            for (int k = 0; k < 3; ++k) o->position[k] = lerpf((float)c[k], (float)(c[k] + (k == a)), t);
+                            normal_trilinear(nrm, o->position, o->normal);
+                        }
+                        ++nv;
+                    }
+                }
+        for (int cell = 0; cell < 512; ++cell) {
+            const int cx = cell & 7, cy = (cell >> 3) & 7, cz = cell >> 6;
+            const int flag = (int)flags[cell];
+            for (int i = 0; i < 5; ++i) {
+                const int32_t *row = g_vert + flag * 15 + i * 3;
+                if (row[0] < 0) continue;
+                if (indices) {
+                    if (T >= tri_capacity) return -1;
+                    const int order[3] = {row[0], row[2], row[1]};
+                    for (int k = 0; k < 3; ++k) {
+                        const int e = order[k], a = k_edge_conn[e][0], bb = k_edge_conn[e][1];
+                        int lo[3], axis = 0;
+                        for (int q = 0; q < 3; ++q) {
+                            const int oa = k_vert_off[a][q], ob = k_vert_off[bb][q];
+                            if (oa != ob) axis = q;
+                            lo[q] = (q == 0 ? cx : (q == 1 ? cy : cz)) + (oa < ob ? oa : ob);
+                        }
+                        indices[3 * T + k] = vid[lo[0] + lo[1] * SS + lo[2] * SS2][axis];
+                    }
+                }
+                ++T;
+            }
+        }
+        V += nv;
+    }
+    if (block_vertex_offsets) block_vertex_offsets[n_blocks] = (int32_t)V;
+    if (block_tri_offsets) block_tri_offsets[n_blocks] = (int32_t)T;
+    if (n_vertices) *n_vertices = V;
+    return T;
+}

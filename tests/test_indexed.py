@@ -1,0 +1,114 @@
+"""Indexed (welded) output, VTMC_OUTPUT_INDEXED: vertices + block-local indices instead of 76-byte
+records.  The reference has no such format (it welds on the CPU with Mesh.Optimize(),
+VoxelTerrain.cs:460), so the bar is set two ways: (i) indices, vertex order and all offsets
+bit-exact against the oracle's restatement of the welding rule, vertex floats within 1e-5;
+(ii) DE-INDEXING the GPU mesh reproduces the reference-format soup of the soup oracle within 1e-5 --
+which ties the new format to the reference's own arithmetic."""
+import numpy as np
+import pytest
+
+import fields
+
+ATOL = 1e-5
+FLOATS = ("p0", "p1", "p2", "n0", "n1", "n2")
+
+
+def test_oracle_welded_mesh_deindexes_to_the_soup(oracle_mod):
+    g = oracle_mod.density_volume("perlin3d", 32)
+    tris, offs, _ = oracle_mod.extract_grid(g)
+    verts, idx, voffs, toffs = oracle_mod.extract_grid_indexed(g)
+    assert np.array_equal(toffs, offs) and len(idx) == len(tris)
+    assert 0.4 < len(verts) / len(tris) < 0.8                      # ~T/2 plus block-boundary duplicates
+    counts = np.diff(voffs)
+    block = np.repeat(np.arange(len(toffs) - 1), np.diff(toffs))
+    assert (idx >= 0).all() and (idx < counts[block][:, None]).all()   # block-local, in range
+    back = oracle_mod.deindex(verts, idx, voffs, toffs)
+    assert np.array_equal(back["block"], tris["block"])
+    assert max(np.abs(back[f] - tris[f]).max() for f in FLOATS) <= 2e-6
+    # every vertex is referenced, and a closed sphere inside ONE block is a 2-manifold: V - E + F = 2
+    used = np.zeros(len(verts), bool)
+    used[(idx + voffs[block][:, None]).ravel()] = True
+    assert used.all()
+    s = fields.sphere((8, 8, 8), (4.2, 3.9, 4.1), 2.7)
+    v, i, vo, to = oracle_mod.extract_grid_indexed(s)
+    edges = {tuple(sorted((int(a), int(b)))) for t in i for a, b in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0]))}
+    assert len(v) - len(edges) + len(i) == 2
+
+
+@pytest.fixture(scope="module")
+def ex():
+    import torch
+    assert torch.cuda.is_available()
+    import volumetricterrain_amd as vt
+    e = vt.Extractor(0)
+    yield e
+    e.close()
+
+
+def check_against_oracle(ex, oracle_mod, g, blocks=None, exact_floats=False):
+    want_v, want_i, want_vo, want_to = oracle_mod.extract_grid_indexed(g, blocks)
+    soup, _, _ = oracle_mod.extract_grid(g, blocks, threads=8)
+    T = ex.extract_grid(g, blocks)
+    assert T == len(want_i)
+    verts, idx, voffs, toffs = ex.read_indexed_mesh()
+    assert np.array_equal(voffs, want_vo) and np.array_equal(toffs, want_to)
+    assert np.array_equal(idx, want_i)
+    for f in ("position", "normal"):
+        nan_w = np.isnan(want_v[f])
+        assert np.array_equal(np.isnan(verts[f]), nan_w)
+        d = np.abs(np.where(nan_w, 0, verts[f]) - np.where(nan_w, 0, want_v[f]))
+        worst = float(d.max()) if d.size else 0.0
+        assert worst <= (0.0 if exact_floats else ATOL), (f, worst)
+    back = oracle_mod.deindex(verts, idx, voffs, toffs)
+    assert np.array_equal(back["block"], soup["block"])
+    for f in FLOATS:
+        ok = ~np.isnan(soup[f])
+        assert np.abs(back[f][ok] - soup[f][ok]).max(initial=0.0) <= ATOL
+    return len(verts), T
+
+
+@pytest.mark.gpu
+def test_gpu_indexed_matches_oracle(ex, oracle_mod):
+    try:
+        ex.set_output_mode(True)
+        # dense streaming classify (x fastest), the C# z-fastest layout, ragged sizes, random fields
+        check_against_oracle(ex, oracle_mod, oracle_mod.density_volume("perlin3d", 64))
+        check_against_oracle(ex, oracle_mod, oracle_mod.density_volume("perlin3d", 32, order="z"))
+        for n in ((40, 16, 24), (72, 8, 16), (8, 8, 8)):
+            check_against_oracle(ex, oracle_mod, fields.random_field(n, seed=n[0]))
+        # a dirty list in arbitrary order
+        g = oracle_mod.density_volume("perlin3d", 64)
+        blocks = oracle_mod.all_blocks(64, 64, 64)
+        sel = blocks[np.random.default_rng(2).permutation(len(blocks))[:300]]
+        check_against_oracle(ex, oracle_mod, g, sel)
+        # exact arithmetic mode: the welded floats are the oracle's, bit for bit
+        ex.set_tuning(emit_fast_math=0)
+        check_against_oracle(ex, oracle_mod, oracle_mod.density_volume("perlin3d", 32), exact_floats=True)
+        ex.set_tuning(emit_fast_math=1)
+        # empty input and analytic plane: 2*W*H triangles on (W+1)*(H+1) lattice columns per block row
+        assert ex.extract_grid(fields.constant((16, 8, 8), -1.0)) == 0
+        v, i, vo, to = ex.read_indexed_mesh()
+        assert len(v) == 0 and len(i) == 0 and (vo == 0).all() and (to == 0).all()
+        nv, T = check_against_oracle(ex, oracle_mod, fields.plane((32, 16, 32), 5.375))
+        assert T == 2 * 32 * 32 and nv == 16 * 81                 # 4 x 4 blocks in the layer, 9 x 9 vertices each
+    finally:
+        ex.set_tuning(emit_fast_math=1)
+        ex.set_output_mode(False)
+    # back in soup mode the indexed getters refuse
+    import volumetricterrain_amd as vt
+    ex.extract_grid(oracle_mod.density_volume("perlin3d", 32))
+    with pytest.raises(vt.VtmcError):
+        ex.read_indexed_mesh()
+
+
+@pytest.mark.gpu
+def test_gpu_indexed_config_256(ex, oracle_mod):
+    """BASELINE config[1] in indexed form: counts, offsets and indices against the oracle; bytes."""
+    g = oracle_mod.density_volume("perlin3d", 256)
+    try:
+        ex.set_output_mode(True)
+        nv, T = check_against_oracle(ex, oracle_mod, g)
+    finally:
+        ex.set_output_mode(False)
+    assert T == 2655156
+    assert (24 * nv + 12 * T) / (76.0 * T) < 0.4                  # < 40 % of the soup's bytes

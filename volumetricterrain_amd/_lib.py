@@ -17,6 +17,10 @@ TRI_DTYPE = np.dtype([("p0", "<f4", 3), ("p1", "<f4", 3), ("p2", "<f4", 3),
                       ("block", "<i4")])
 assert TRI_DTYPE.itemsize == 76  # CSTriangle.stride, VoxelTerrain.cs:36
 
+VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3)])   # vtmc_vertex
+assert VERTEX_DTYPE.itemsize == 24
+OUTPUT_SOUP, OUTPUT_INDEXED = 0, 1
+
 OK = 0
 ERR_INVALID_ARG, ERR_DIMS, ERR_CAPACITY, ERR_DEVICE, ERR_NO_RESULT, ERR_TOO_LARGE = -1, -2, -3, -4, -5, -6
 FLAG_WANT_CASES, FLAG_NO_DENSE_PATH = 1, 2
@@ -29,6 +33,7 @@ SYMBOLS = [
     "vtmc_reserve_triangles", "vtmc_last_stage_ms", "vtmc_set_tuning", "vtmc_density_fill_device",
     "vtmc_terrain_init", "vtmc_terrain_update", "vtmc_terrain_dirty_blocks", "vtmc_terrain_read_samples",
     "vtmc_terrain_device_grid", "vtmc_copy_volume_counts_device", "vtmc_density_fill_device_async",
+    "vtmc_set_output_mode", "vtmc_last_vertex_count", "vtmc_read_indexed_mesh", "vtmc_device_indexed_results",
 ]
 
 MOD_PLANE, MOD_SPHERE, MOD_CYLINDER = 0, 1, 2
@@ -101,6 +106,10 @@ def load():
     L.vtmc_density_fill_device.argtypes = [vp, P(DensityParams), vp, i32, i32, i32, i32,
                                            i64, i64, i64, i64, vp, vp]
     L.vtmc_density_fill_device_async.argtypes = L.vtmc_density_fill_device.argtypes
+    L.vtmc_set_output_mode.argtypes = [vp, i32]
+    L.vtmc_last_vertex_count.argtypes = [vp, P(i32)]
+    L.vtmc_read_indexed_mesh.argtypes = [vp, vp, i64, vp, i64, vp, vp]
+    L.vtmc_device_indexed_results.argtypes = [vp, P(vp), P(vp), P(vp), P(vp)]
     L.vtmc_terrain_init.argtypes = [vp, i32, i32, i32, ctypes.c_float, P(ctypes.c_float * 3), ctypes.c_uint64]
     L.vtmc_terrain_update.argtypes = [vp, vp, i32, P(i32), P(i32)]
     L.vtmc_terrain_dirty_blocks.argtypes = [vp, vp, i32, P(i32)]

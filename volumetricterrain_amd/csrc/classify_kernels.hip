@@ -19,7 +19,8 @@ namespace vtmc {
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void classify_blocks_kernel(BlockSpace sp, DeviceTables tb,
                                                                uint32_t *__restrict__ counts,
-                                                               uint8_t *__restrict__ cases)
+                                                               uint8_t *__restrict__ cases,
+                                                               uint32_t *__restrict__ vcounts)
 {
     __shared__ float s_tile[kWavesPerWg][1000];
     __shared__ unsigned char s_trinum[256];
@@ -48,6 +49,23 @@ __global__ __launch_bounds__(256) void classify_blocks_kernel(BlockSpace sp, Dev
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off);
         if (lane == 0) counts[b] = total;
+        if (vcounts) {
+            // welded vertices = lattice edges of the 9^3 lattice with a sign change, enumerated as the
+            // indexed emit does: point p = x + 9y + 81z, axes x, y, z
+            unsigned v = 0;
+            for (int p0 = 0; p0 < 729; p0 += 64) {
+                const int p = p0 + lane;
+                if (p < 729) {
+                    const int x = p % 9, y = (p / 9) % 9, z = p / 81;
+                    const float *q = tile + x + 10 * y + 100 * z;
+                    const bool s0 = q[0] > 0.f;
+                    v += (x < 8 && s0 != (q[1] > 0.f)) + (y < 8 && s0 != (q[10] > 0.f)) + (z < 8 && s0 != (q[100] > 0.f));
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0) vcounts[b] = v;
+        }
     }
 }
 
@@ -59,8 +77,10 @@ __global__ __launch_bounds__(256) void classify_blocks_kernel(BlockSpace sp, Dev
 // reduced over 8-lane groups.  Each sample is requested once per brick (9/8 x 9/8 halo re-reads
 // are served by L2).  No per-cell output: cases are recomputed by the emit kernel from its LDS tile.
 // ----------------------------------------------------------------------------------------------
+template <bool WANT_V>
 __global__ __launch_bounds__(256) void classify_dense_kernel(BlockSpace sp, DeviceTables tb,
                                                               uint32_t *__restrict__ counts,
+                                                              uint32_t *__restrict__ vcounts,
                                                               int nsegx, int n_bricks, int n_wgs, int ablate)
 {
     __shared__ unsigned char s_trinum[256];
@@ -91,13 +111,21 @@ __global__ __launch_bounds__(256) void classify_dense_kernel(BlockSpace sp, Devi
     xe = xe < sp.nx + 1 ? xe : sp.nx + 1;
     const float *brick_base = sp.base + v * sp.sv + (8ll * by) * sp.sy + (8ll * bz) * sp.sz;
 
-    unsigned total = classify_brick_column(sp, s_trinum, brick_base, gx, gxc, xe, lane, ablate);
+    unsigned vc = 0;
+    unsigned total = classify_brick_column<WANT_V>(sp, s_trinum, brick_base, gx, gxc, xe, lane, ablate, &vc);
     // 8-lane group sums = per-block counts
     total += __shfl_xor(total, 1);
     total += __shfl_xor(total, 2);
     total += __shfl_xor(total, 4);
     const int bx = segx * 8 + (lane >> 3);
-    if ((lane & 7) == 0 && bx < sp.nbx) counts[v * sp.bpv + bx + sp.nbx * (by + sp.nby * bz)] = total;
+    const int bid = v * sp.bpv + bx + sp.nbx * (by + sp.nby * bz);
+    if ((lane & 7) == 0 && bx < sp.nbx) counts[bid] = total;
+    if (WANT_V) {
+        vc += __shfl_xor(vc, 1);
+        vc += __shfl_xor(vc, 2);
+        vc += __shfl_xor(vc, 4);
+        if ((lane & 7) == 0 && bx < sp.nbx) vcounts[bid] = vc;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -218,7 +246,7 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restr
         int i = base + k;
         if (i < n) {
             offsets[i] = off;
-            if (c[k] != 0u) active_list[aoff++] = i;
+            if (active_list && c[k] != 0u) active_list[aoff++] = i;
             off += c[k];
             if (i == n - 1) offsets[n] = off;
         }
@@ -240,26 +268,30 @@ __global__ void volume_counts_kernel(const uint32_t *__restrict__ offsets, int b
 // launch wrappers
 // ----------------------------------------------------------------------------------------------
 hipError_t launch_classify_blocks(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
-                                  uint8_t *cases_or_null, int n_cus, hipStream_t stream)
+                                  uint8_t *cases_or_null, uint32_t *vcounts_or_null, int n_cus, hipStream_t stream)
 {
     int wgs = (sp.n_blocks + kWavesPerWg - 1) / kWavesPerWg;
     int cap = n_cus * 8;
     if (wgs > cap) wgs = cap;
     if (wgs < 1) wgs = 1;
-    hipLaunchKernelGGL(classify_blocks_kernel, dim3(wgs), dim3(256), 0, stream, sp, tb, counts, cases_or_null);
+    hipLaunchKernelGGL(classify_blocks_kernel, dim3(wgs), dim3(256), 0, stream, sp, tb, counts, cases_or_null, vcounts_or_null);
     return hipGetLastError();
 }
 
 hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
-                                 int ablate, hipStream_t stream)
+                                 uint32_t *vcounts_or_null, int ablate, hipStream_t stream)
 {
     const int nsegx = (sp.nx + 63) / 64;
     const long long n_vol = sp.n_blocks / sp.bpv;
     long long n_bricks = n_vol * sp.nbz * sp.nby * nsegx;
     long long n_wgs = (n_bricks + kWavesPerWg - 1) / kWavesPerWg;
     if (n_wgs > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(classify_dense_kernel, dim3((unsigned)n_wgs), dim3(256), 0, stream, sp, tb, counts, nsegx,
-                       (int)n_bricks, (int)n_wgs, ablate);
+    if (vcounts_or_null)
+        hipLaunchKernelGGL((classify_dense_kernel<true>), dim3((unsigned)n_wgs), dim3(256), 0, stream, sp, tb, counts, vcounts_or_null,
+                           nsegx, (int)n_bricks, (int)n_wgs, ablate);
+    else
+        hipLaunchKernelGGL((classify_dense_kernel<false>), dim3((unsigned)n_wgs), dim3(256), 0, stream, sp, tb, counts, vcounts_or_null,
+                           nsegx, (int)n_bricks, (int)n_wgs, ablate);
     return hipGetLastError();
 }
 

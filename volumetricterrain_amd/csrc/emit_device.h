@@ -236,5 +236,188 @@ __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_v
     if (pending > 0) emit_flush2<FAST>(L, pending, tri_base, block_id, out, lane, ablate);
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Indexed (welded) output of one block -- new in the build (the reference welds later, on the CPU,
+// with Mesh.Optimize(), VoxelTerrain.cs:460).  A mesh vertex lives on a lattice edge with a sign
+// change; all cells around that edge share it:
+//   vertices : one 24-byte record {position, normal} per such edge of the block's 9^3 lattice,
+//              ordered by lattice point p = x + 9y + 81z, then axis x, y, z;
+//   indices  : three block-local int32 per triangle, canonical triangle order (as the soup).
+// The vertex is evaluated from the edge's LOW endpoint (the orientation the reference uses for cube
+// edges 0, 1, 4, 5, 8..11); where the reference walks an edge backwards (edges 2, 3, 6, 7) its
+// t' = 1 - t differs from this one by rounding only (<= ~1e-6 in cell units, bar 1e-5).
+// ----------------------------------------------------------------------------------------------
+constexpr int kVertDwords = 6;  // 24-byte vertex record
+
+struct __attribute__((aligned(16))) EmitLdsIdx {
+    float tile[1000];
+    unsigned slot[kSlotCap];        // triangle slot -> cell | edge triple << 9
+    unsigned short acell[512];      // active cells of the block, ascending cell id
+    unsigned char cases[512];
+    unsigned short vmap[736];       // lattice point -> first vertex id | axis flags << 12
+    unsigned short vlist[192];      // vertices of the current 64-point step: point << 2 | axis
+    float stage[64 * kVertDwords + 4];
+};
+static_assert(sizeof(EmitLdsIdx) % 16 == 0 && offsetof(EmitLdsIdx, stage) % 16 == 0, "stage must stay 16-byte aligned");
+
+// streams `n_dw` staged dwords (L->stage + sh ...) to out + d0 with 16-byte stores; sh = d0 & 3
+__device__ __forceinline__ void stream_out_staged(const float *stage, float *__restrict__ out, size_t d0, int sh, int n_dw, int lane)
+{
+    const int lo = sh, hi = sh + n_dw;
+    float *gal = out + (d0 - sh);  // 16-byte aligned
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int body_lo = (lo + 3) & ~3, body_hi = hi & ~3;
+    for (int q4 = body_lo + 4 * lane; q4 < body_hi; q4 += 256)
+        __builtin_nontemporal_store(*reinterpret_cast<const v4f *>(stage + q4), reinterpret_cast<v4f *>(gal + q4));
+    const int k = lane & 3;
+    const int idx = lane < 4 ? lo + k : body_hi + k;
+    const bool on = lane < 4 ? (idx < body_lo && idx < hi) : (lane < 8 && idx < hi && idx >= body_lo);
+    if (on) __builtin_nontemporal_store(stage[idx], gal + idx);
+}
+
+template <bool FAST>
+__device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_vert, size_t tri_base, int tri_budget,
+                                                   size_t vert_base, int vert_budget, float *__restrict__ out_vertices,
+                                                   int *__restrict__ out_indices, int lane)
+{
+    const float *tile = L->tile;
+    // pass 1: cases + compaction of the active cells (as the soup path)
+    const int t0 = (lane & 7) + 10 * (lane >> 3);
+    int n_act = 0;
+    unsigned lo = layer_nibble(tile, t0, 0);
+#pragma unroll
+    for (int z = 0; z < 8; ++z) {
+        const unsigned hi = layer_nibble(tile, t0, z + 1);
+        const unsigned cs = lo | (hi << 4);
+        lo = hi;
+        const int cell = 64 * z + lane;
+        L->cases[cell] = (unsigned char)cs;
+        const bool act = ((cs + 1u) & 0xFFu) > 1u;
+        const u64 m = __builtin_amdgcn_ballot_w64(act);
+        if (act) L->acell[n_act + (int)lanes_below(m)] = (unsigned short)cell;
+        n_act += __builtin_popcountll(m);
+    }
+
+    // vertices: number the sign-change edges 64 lattice points at a time and emit them at once
+    int vrun = 0;
+    for (int p0 = 0; p0 < 729; p0 += 64) {
+        const int p = p0 + lane;
+        unsigned flags = 0;
+        if (p < 729) {
+            const int x = p % 9, y = (p / 9) % 9, z = p / 81;
+            const float *q = tile + x + 10 * y + 100 * z;
+            const bool s0 = q[0] > 0.f;
+            flags = (unsigned)(x < 8 && s0 != (q[1] > 0.f)) | ((unsigned)(y < 8 && s0 != (q[10] > 0.f)) << 1) |
+                    ((unsigned)(z < 8 && s0 != (q[100] > 0.f)) << 2);
+        }
+        unsigned step_total;
+        const unsigned pre = wave_prefix3((unsigned)__builtin_popcount(flags), step_total);
+        if (p < 729) L->vmap[p] = (unsigned short)((unsigned)(vrun + (int)pre) | (flags << 12));
+        {
+            unsigned k = pre;
+#pragma unroll
+            for (unsigned a = 0; a < 3; ++a)
+                if (flags & (1u << a)) L->vlist[k++] = (unsigned short)(((unsigned)p << 2) | a);
+        }
+        VTMC_WAVE_SYNC();
+        int n_v = (int)step_total;
+        if (vrun + n_v > vert_budget) n_v = vert_budget - vrun > 0 ? vert_budget - vrun : 0;  // never outside the block's slice
+        for (int s0 = 0; s0 < n_v; s0 += 64) {
+            const int s = s0 + lane;
+            const size_t d0 = (vert_base + (size_t)(vrun + s0)) * kVertDwords;
+            const int sh = (int)(d0 & 3);
+            if (s < n_v) {
+                const unsigned ent = L->vlist[s];
+                const unsigned axis = ent & 3u;
+                const int pp = (int)(ent >> 2);
+                const int c[3] = {pp % 9, (pp / 9) % 9, pp / 81};
+                const int sk = axis == 0 ? 1 : (axis == 1 ? 10 : 100);
+                const int tl = c[0] + 10 * c[1] + 100 * c[2];
+                const float va = tile[tl], vb = tile[tl + sk];
+                const float t = FAST ? __builtin_amdgcn_fmed3f(-va * __builtin_amdgcn_rcpf(vb - va), 0.0f, 1.0f) : (-va) / (vb - va);
+                const int ck = axis == 0 ? c[0] : (axis == 1 ? c[1] : c[2]);
+                const float q = (float)ck + t;
+                const float fq = floorf(q);
+                const float w = q - fq;
+                float g0[3], g1[3];
+                lattice_gradient(tile, tl + ((int)fq - ck) * sk, g0);
+                lattice_gradient(tile, tl + ((int)ceilf(q) - ck) * sk, g1);
+                normalise<FAST>(g0);
+                normalise<FAST>(g1);
+                float *rec = L->stage + sh + lane * kVertDwords;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    rec[a] = axis == (unsigned)a ? q : (float)c[a];
+                    rec[3 + a] = FAST ? __builtin_fmaf(w, g1[a] - g0[a], g0[a]) : g0[a] + w * (g1[a] - g0[a]);
+                }
+            }
+            VTMC_WAVE_SYNC();
+            const int cnt = n_v - s0 < 64 ? n_v - s0 : 64;
+            stream_out_staged(L->stage, out_vertices, d0, sh, cnt * kVertDwords, lane);
+            VTMC_WAVE_SYNC();
+        }
+        vrun += (int)step_total;
+    }
+
+    // pass 2 + index flush: triangle slots, 64 active cells per step
+    auto flush = [&](int pending, size_t base) {
+        VTMC_WAVE_SYNC();
+        for (int s0 = 0; s0 < pending; s0 += 64) {
+            const int s = s0 + lane;
+            const size_t d0 = (base + (size_t)s0) * 3;
+            const int sh = (int)(d0 & 3);
+            if (s < pending) {
+                const unsigned sc = L->slot[s];
+                const int cell = sc & 511u;
+                const unsigned trip = sc >> 9;
+                const int cx = cell & 7, cy = (cell >> 3) & 7, cz = cell >> 6;
+                const unsigned e[3] = {trip & 15u, (trip >> 8) & 15u, (trip >> 4) & 15u};  // winding swap, MarchingCube.compute:147-157
+                int *rec = reinterpret_cast<int *>(L->stage) + sh + lane * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const unsigned g = (unsigned)(kEdgeGeom >> (5u * e[k])) & 31u;
+                    const unsigned axis = g >> 3;
+                    int lx = cx + (int)(g & 1u), ly = cy + (int)((g >> 1) & 1u), lz = cz + (int)((g >> 2) & 1u);
+                    // endpoint a on the far end: the lattice edge starts one step back along the axis
+                    lx -= axis == 0 ? (int)(g & 1u) : 0;
+                    ly -= axis == 1 ? (int)((g >> 1) & 1u) : 0;
+                    lz -= axis == 2 ? (int)((g >> 2) & 1u) : 0;
+                    const unsigned vm = L->vmap[lx + 9 * ly + 81 * lz];
+                    rec[k] = (int)((vm & 0xFFFu) + (unsigned)__builtin_popcount((vm >> 12) & ((1u << axis) - 1u)));
+                }
+            }
+            VTMC_WAVE_SYNC();
+            const int cnt = pending - s0 < 64 ? pending - s0 : 64;
+            stream_out_staged(L->stage, reinterpret_cast<float *>(out_indices), d0, sh, cnt * 3, lane);
+            VTMC_WAVE_SYNC();
+        }
+    };
+    int pending = 0;
+    for (int c0 = 0; c0 < n_act; c0 += 64) {
+        if (pending > kSlotCap - 320) {  // wave-uniform
+            const int n_out = pending < tri_budget ? pending : tri_budget;
+            flush(n_out, tri_base);
+            tri_base += n_out;
+            tri_budget -= n_out;
+            pending = 0;
+        }
+        const int idx = c0 + lane;
+        const bool valid = idx < n_act;
+        const unsigned cell = valid ? L->acell[idx] : 0u;
+        const u64 vw = valid ? s_vert[L->cases[cell]] : 0ull;
+        const unsigned n = (unsigned)(vw >> 60);
+        unsigned step_total;
+        const unsigned pre_n = wave_prefix3(n, step_total);
+        unsigned *dst = L->slot + pending + pre_n;
+#pragma unroll
+        for (unsigned i = 0; i < 5; ++i)
+            if (i < n) dst[i] = cell | (((unsigned)(vw >> (12 * i)) & 0xFFFu) << 9);
+        pending += (int)step_total;
+    }
+    if (pending > tri_budget) pending = tri_budget;
+    if (pending > 0) flush(pending, tri_base);
+}
+
 }  // namespace vtmc
 #endif

@@ -5,6 +5,8 @@
 // triangles land at offsets fixed by the scan (canonical order) instead of an atomic append.
 #include "emit_device.h"
 
+#include <type_traits>
+
 namespace vtmc {
 
 // ----------------------------------------------------------------------------------------------
@@ -16,14 +18,19 @@ namespace vtmc {
 //     (16 loads per lane, scalar base + 32-bit lane offsets hoisted out of the block loop);
 //   * per-block work: emit_block_from_tile (emit_device.h).
 // ----------------------------------------------------------------------------------------------
-template <bool FAST>
+//   INDEXED: welded vertices + block-local indices (emit_block_indexed) instead of 76-byte records;
+//   `out` then is the vertex buffer, voffsets / vcapacity / out_indices its extra operands.
+template <bool FAST, bool INDEXED>
 __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables tb,
                                                     const uint32_t *__restrict__ offsets,
                                                     const int32_t *__restrict__ active_list,
                                                     const uint32_t *__restrict__ totals, uint32_t capacity,
-                                                    float *__restrict__ out, int group_log2, int ablate, unsigned *__restrict__ queue, int sub_log2)
+                                                    float *__restrict__ out, int group_log2, int ablate, unsigned *__restrict__ queue, int sub_log2,
+                                                    const uint32_t *__restrict__ voffsets, const uint32_t *__restrict__ vtotals,
+                                                    uint32_t vcapacity, int *__restrict__ out_indices)
 {
-    __shared__ EmitLds2 s_lds[kWavesPerWg];
+    using Lds = typename std::conditional<INDEXED, EmitLdsIdx, EmitLds2>::type;
+    __shared__ Lds s_lds[kWavesPerWg];
     __shared__ u64 s_vert[256];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -36,8 +43,9 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
     const uint32_t total_tris = totals[0];
     const int n_active = (int)totals[1];
     if (total_tris > capacity) return;  // host grows the buffer and re-launches (vtmc_api.hip)
+    if (INDEXED && vtotals[0] > vcapacity) return;
 
-    EmitLds2 *L = &s_lds[wave];
+    Lds *L = &s_lds[wave];
 
     // loop-invariant byte offsets of this lane's 16 tile samples relative to the block origin, and
     // their LDS destinations (lane index walks the stride-1 axis)
@@ -114,7 +122,11 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
         request();  // ticket for the block after next; collected at the bottom of this iteration
         VTMC_WAVE_SYNC();
 
-        emit_block_from_tile<FAST>(L, s_vert, tri_base, budget, b, out, lane, ablate);
+        if constexpr (INDEXED)
+            emit_block_indexed<FAST>(L, s_vert, tri_base, budget, (size_t)voffsets[b], (int)(voffsets[b + 1] - voffsets[b]), out,
+                                     out_indices, lane);
+        else
+            emit_block_from_tile<FAST>(L, s_vert, tri_base, budget, b, out, lane, ablate);
         ai = ai_next;
         ai_next = collect();
     }
@@ -129,10 +141,28 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
     wgs = (wgs + 7) & ~7;  // the XCD sweep needs a multiple of 8
     dim3 g(wgs), blk(256);
     float *o = (float *)triangles;
+    unsigned *q = tune.emit_dynamic ? queue : nullptr;
     if (tune.emit_fast_math)
-        hipLaunchKernelGGL((emit_kernel<true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, tune.emit_dynamic ? queue : nullptr, tune.emit_sub_log2);
+        hipLaunchKernelGGL((emit_kernel<true, false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr);
     else
-        hipLaunchKernelGGL((emit_kernel<false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, tune.emit_dynamic ? queue : nullptr, tune.emit_sub_log2);
+        hipLaunchKernelGGL((emit_kernel<false, false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets, const uint32_t *voffsets,
+                               const int32_t *active_list, const uint32_t *totals, const uint32_t *vtotals, uint32_t tri_capacity,
+                               uint32_t vert_capacity, void *vertices, void *indices, int n_cus, const Tuning &tune, unsigned *queue,
+                               hipStream_t stream)
+{
+    int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : 3;
+    int wgs = n_cus * per_cu;
+    wgs = (wgs + 7) & ~7;
+    dim3 g(wgs), blk(256);
+    unsigned *q = tune.emit_dynamic ? queue : nullptr;
+    if (tune.emit_fast_math)
+        hipLaunchKernelGGL((emit_kernel<true, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, 0, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices);
+    else
+        hipLaunchKernelGGL((emit_kernel<false, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, 0, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices);
     return hipGetLastError();
 }
 

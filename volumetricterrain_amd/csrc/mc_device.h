@@ -97,9 +97,14 @@ __device__ __forceinline__ unsigned extract9(u64 e0, u64 e1, int r0)
 // planes, the case of a cell (CollectTriNum.compute:27-51) is assembled from 4 row bit-pairs,
 // triangle counts come from the 256-byte LDS table.  Returns the triangle count of this lane's
 // 8 x 8 cell column; the sum over an 8-lane group is a block's count.
+// WANT_V: *vcount receives this lane's share of the block's WELDED vertex count = lattice edges with
+// a sign change (every such edge carries exactly one mesh vertex): the x-, y- and z-edges starting
+// in this lane's 9 x 9 sample column, plus -- for the last lane of an 8-lane group -- the y- and
+// z-edges of the block's far x = 8 plane.  Same enumeration as the indexed emit (emit_device.h).
+template <bool WANT_V = false>
 __device__ __forceinline__ unsigned classify_brick_column(const BlockSpace &sp, const unsigned char *s_trinum,
                                                           const float *brick_base, int gx, int gxc, int xe, int lane,
-                                                          int ablate = 0)
+                                                          int ablate = 0, unsigned *vcount = nullptr)
 {
     // 81 row loads, lane-contiguous
     float val[9][9];
@@ -145,6 +150,23 @@ __device__ __forceinline__ unsigned classify_brick_column(const BlockSpace &sp, 
 
     unsigned total = 0;
     const bool uniform = (or_all == 0u) || (and_all == 0x1FFu);
+    if (WANT_V) {
+        unsigned v = 0;
+        if (!uniform) {
+            const bool far_plane = (lane & 7) == 7;
+#pragma unroll
+            for (int zz = 0; zz < 9; ++zz) {
+                v += __builtin_popcount((A[zz] ^ N[zz]) & 0x1FFu);            // x-edges
+                v += __builtin_popcount((A[zz] ^ (A[zz] >> 1)) & 0xFFu);      // y-edges
+                if (zz < 8) v += __builtin_popcount((A[zz] ^ A[zz + 1]) & 0x1FFu);  // z-edges
+                if (far_plane) {
+                    v += __builtin_popcount((N[zz] ^ (N[zz] >> 1)) & 0xFFu);
+                    if (zz < 8) v += __builtin_popcount((N[zz] ^ N[zz + 1]) & 0x1FFu);
+                }
+            }
+        }
+        *vcount = gx >= sp.nx ? 0u : v;
+    }
     if (__builtin_amdgcn_ballot_w64(!uniform) != 0) {
         // NIB[zz] nibble yy = corners (0,1,2,3) of the cell column at sample layer zz
         unsigned NIB[9];

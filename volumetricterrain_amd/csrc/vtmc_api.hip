@@ -44,6 +44,10 @@ struct vtmc_ctx {
     DeviceTables tables{nullptr, nullptr};
     DevBuf d_vert, d_trinum;
     DevBuf counts, offsets, active, partials, totals, volcounts, cases, tris, input, list, perm, origins, sweep;
+    DevBuf vcounts, voffsets, vpartials, vtotals, verts, indices;  // indexed output
+    int output_mode = VTMC_OUTPUT_SOUP;
+    bool last_indexed = false;
+    int64_t last_verts = 0;
     uint32_t *h_totals = nullptr;  // pinned: {T, nActive} of the scan, or the sweep kernel's kCtrlWords control words
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0..3] stage timing, [4] staging copies
     float stage_ms[4] = {0, 0, 0, 0};
@@ -119,6 +123,12 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
         ctx->last_blocks = 0;
         ctx->last_volumes = n_volumes;
         ctx->last_tris = 0;
+        ctx->last_verts = 0;
+        ctx->last_indexed = ctx->output_mode == VTMC_OUTPUT_INDEXED;
+        if (ctx->last_indexed) {
+            if (int rc = ensure(ctx, ctx->voffsets, sizeof(uint32_t))) return rc;
+            VTMC_HIP(ctx, hipMemsetAsync(ctx->voffsets.p, 0, sizeof(uint32_t), stream));
+        }
         memset(ctx->stage_ms, 0, sizeof ctx->stage_ms);
         if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t))) return rc;
         VTMC_HIP(ctx, hipMemsetAsync(ctx->offsets.p, 0, sizeof(uint32_t), stream));
@@ -135,9 +145,10 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
         if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * ((size_t)1 << 20))) return rc;
 
     const bool dense = !sp.list && sp.sx == 1 && sp.nx >= 32 && !(flags & (VTMC_FLAG_WANT_CASES | VTMC_FLAG_NO_DENSE_PATH));
-    int64_t T_found = 0;
+    const bool indexed = ctx->output_mode == VTMC_OUTPUT_INDEXED;
+    int64_t T_found = 0, V_found = 0;
 
-    if (dense && ctx->tune.sweep) {
+    if (dense && ctx->tune.sweep && !indexed) {
         // single pass: classify + chained scan + emit in one kernel (sweep_kernels.hip).  The kernel
         // counts every triangle but writes only those below the buffer's capacity, so a buffer that
         // turns out too small costs one more launch (the first call on a new field, typically).
@@ -178,14 +189,58 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
         d_cases = (uint8_t *)ctx->cases.p;
     }
 
+    uint32_t *d_vcounts = nullptr;
+    if (indexed) {
+        if (int rc = ensure(ctx, ctx->vcounts, sizeof(uint32_t) * (size_t)B)) return rc;
+        if (int rc = ensure(ctx, ctx->voffsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
+        if (int rc = ensure(ctx, ctx->vpartials, sizeof(uint32_t) * 2 * (size_t)n_tiles)) return rc;
+        if (int rc = ensure(ctx, ctx->vtotals, sizeof(uint32_t) * 64)) return rc;
+        if (!ctx->verts.p)
+            if (int rc = ensure(ctx, ctx->verts, sizeof(vtmc_vertex) * ((size_t)1 << 19))) return rc;
+        if (!ctx->indices.p)
+            if (int rc = ensure(ctx, ctx->indices, sizeof(int32_t) * 3 * ((size_t)1 << 20))) return rc;
+        d_vcounts = (uint32_t *)ctx->vcounts.p;
+    }
+
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
-    if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, ctx->tune.classify_ablate, stream));
-    else VTMC_HIP(ctx, launch_classify_blocks(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_cases, ctx->n_cus, stream));
+    if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_vcounts, ctx->tune.classify_ablate, stream));
+    else VTMC_HIP(ctx, launch_classify_blocks(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_cases, d_vcounts, ctx->n_cus, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
     VTMC_HIP(ctx, launch_scan((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p,
                               (int32_t *)ctx->active.p, (uint32_t *)ctx->partials.p, (uint32_t *)ctx->totals.p,
                               sp.bpv, n_volumes, (uint32_t *)ctx->volcounts.p, stream));
+    if (indexed)  // the same scan over the welded-vertex counts: per-block vertex offsets + V
+        VTMC_HIP(ctx, launch_scan(d_vcounts, B, (uint32_t *)ctx->voffsets.p, nullptr, (uint32_t *)ctx->vpartials.p,
+                                  (uint32_t *)ctx->vtotals.p, sp.bpv, 0, nullptr, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
+
+    if (indexed) {
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const size_t tcap = std::min<size_t>(ctx->indices.bytes / (3 * sizeof(int32_t)), 0x7fffffffu);
+            const size_t vcap = std::min<size_t>(ctx->verts.bytes / sizeof(vtmc_vertex), 0x7fffffffu);
+            uint32_t *queue = (uint32_t *)ctx->totals.p + 64;
+            VTMC_HIP(ctx, hipMemsetAsync(queue, 0, kQueueWords * sizeof(uint32_t), stream));
+            VTMC_HIP(ctx, launch_emit_indexed(sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const uint32_t *)ctx->voffsets.p,
+                                              (const int32_t *)ctx->active.p, (const uint32_t *)ctx->totals.p,
+                                              (const uint32_t *)ctx->vtotals.p, (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p,
+                                              ctx->indices.p, ctx->n_cus, ctx->tune, queue, stream));
+            VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
+            VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->totals.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 2, ctx->vtotals.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            VTMC_HIP(ctx, hipStreamSynchronize(stream));
+            const uint32_t T = ctx->h_totals[0], V = ctx->h_totals[2];
+            if (T > 0x7fffffffu || V > 0x7fffffffu) return fail(ctx, VTMC_ERR_TOO_LARGE, "%u triangles / %u vertices exceed the int32 range of the ABI", T, V);
+            T_found = T;
+            V_found = V;
+            if ((size_t)T <= tcap && (size_t)V <= vcap) break;
+            if (attempt == 1) return fail(ctx, VTMC_ERR_DEVICE, "indexed buffers still too small after growing");
+            if ((size_t)T > tcap)
+                if (int rc = ensure(ctx, ctx->indices, sizeof(int32_t) * 3 * ((size_t)T + (size_t)T / 8 + 1024))) return rc;
+            if ((size_t)V > vcap)
+                if (int rc = ensure(ctx, ctx->verts, sizeof(vtmc_vertex) * ((size_t)V + (size_t)V / 8 + 1024))) return rc;
+            VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
+        }
+    } else
 
     for (int attempt = 0; attempt < 2; ++attempt) {
         const size_t cap = std::min<size_t>(ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
@@ -221,6 +276,8 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
     ctx->last_blocks = B;
     ctx->last_volumes = n_volumes;
     ctx->last_tris = T_found;
+    ctx->last_verts = V_found;
+    ctx->last_indexed = indexed;
     if (tri_count) *tri_count = ctx->last_tris;
     return VTMC_OK;
 }
@@ -325,7 +382,8 @@ int32_t vtmc_destroy(vtmc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->d_vert, &ctx->d_trinum, &ctx->counts, &ctx->offsets, &ctx->active, &ctx->partials, &ctx->totals,
-                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->sweep, &ctx->terrain})
+                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->sweep, &ctx->terrain,
+                      &ctx->vcounts, &ctx->voffsets, &ctx->vpartials, &ctx->vtotals, &ctx->verts, &ctx->indices})
         release(*b);
     if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
     for (auto &ev : ctx->ev)
@@ -454,10 +512,63 @@ int32_t vtmc_extract_grid_sharded(vtmc_ctx *ctx, const float *grid, int32_t nx, 
     return VTMC_OK;
 }
 
+int32_t vtmc_set_output_mode(vtmc_ctx *ctx, int32_t mode)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (mode != VTMC_OUTPUT_SOUP && mode != VTMC_OUTPUT_INDEXED) return fail(ctx, VTMC_ERR_INVALID_ARG, "unknown output mode %d", mode);
+    ctx->output_mode = mode;
+    return VTMC_OK;
+}
+
+int32_t vtmc_last_vertex_count(const vtmc_ctx *ctx, int32_t *vertex_count)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->has_result || !ctx->last_indexed) return VTMC_ERR_NO_RESULT;
+    if (vertex_count) *vertex_count = (int32_t)ctx->last_verts;
+    return VTMC_OK;
+}
+
+int32_t vtmc_read_indexed_mesh(vtmc_ctx *ctx, vtmc_vertex *vertices, int64_t vertex_capacity, int32_t *indices, int64_t tri_capacity,
+                               int32_t *block_vertex_offsets, int32_t *block_tri_offsets)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->has_result || !ctx->last_indexed) return fail(ctx, VTMC_ERR_NO_RESULT, "read_indexed_mesh: the last extract did not run in indexed mode");
+    if (vertex_capacity < ctx->last_verts || tri_capacity < ctx->last_tris)
+        return fail(ctx, VTMC_ERR_CAPACITY, "capacity (%lld vertices, %lld triangles) < (%lld, %lld)", (long long)vertex_capacity,
+                    (long long)tri_capacity, (long long)ctx->last_verts, (long long)ctx->last_tris);
+    if ((ctx->last_verts > 0 && !vertices) || (ctx->last_tris > 0 && !indices)) return fail(ctx, VTMC_ERR_INVALID_ARG, "destination is null");
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->last_verts > 0) VTMC_HIP(ctx, hipMemcpy(vertices, ctx->verts.p, sizeof(vtmc_vertex) * (size_t)ctx->last_verts, hipMemcpyDeviceToHost));
+    if (ctx->last_tris > 0) VTMC_HIP(ctx, hipMemcpy(indices, ctx->indices.p, sizeof(int32_t) * 3 * (size_t)ctx->last_tris, hipMemcpyDeviceToHost));
+    const size_t nb = (size_t)ctx->last_blocks + 1;
+    if (block_vertex_offsets) {
+        if (ctx->last_blocks > 0) VTMC_HIP(ctx, hipMemcpy(block_vertex_offsets, ctx->voffsets.p, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost));
+        else block_vertex_offsets[0] = 0;
+    }
+    if (block_tri_offsets) {
+        if (ctx->last_blocks > 0) VTMC_HIP(ctx, hipMemcpy(block_tri_offsets, ctx->offsets.p, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost));
+        else block_tri_offsets[0] = 0;
+    }
+    return VTMC_OK;
+}
+
+int32_t vtmc_device_indexed_results(vtmc_ctx *ctx, const vtmc_vertex **d_vertices, const int32_t **d_indices,
+                                    const uint32_t **d_block_vertex_offsets, const uint32_t **d_block_tri_offsets)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->has_result || !ctx->last_indexed) return fail(ctx, VTMC_ERR_NO_RESULT, "device_indexed_results: the last extract did not run in indexed mode");
+    if (d_vertices) *d_vertices = (const vtmc_vertex *)ctx->verts.p;
+    if (d_indices) *d_indices = (const int32_t *)ctx->indices.p;
+    if (d_block_vertex_offsets) *d_block_vertex_offsets = (const uint32_t *)ctx->voffsets.p;
+    if (d_block_tri_offsets) *d_block_tri_offsets = (const uint32_t *)ctx->offsets.p;
+    return VTMC_OK;
+}
+
 int32_t vtmc_read_triangles(vtmc_ctx *ctx, vtmc_triangle *dst, int64_t capacity, int32_t *block_tri_offsets)
 {
     if (!ctx) return VTMC_ERR_INVALID_ARG;
     if (!ctx->has_result) return fail(ctx, VTMC_ERR_NO_RESULT, "read_triangles before any extract");
+    if (ctx->last_indexed) return fail(ctx, VTMC_ERR_NO_RESULT, "read_triangles: the last extract ran in indexed mode (use vtmc_read_indexed_mesh)");
     if (capacity < ctx->last_tris) return fail(ctx, VTMC_ERR_CAPACITY, "capacity %lld < %lld triangles", (long long)capacity, (long long)ctx->last_tris);
     if (ctx->last_tris > 0 && !dst) return fail(ctx, VTMC_ERR_INVALID_ARG, "dst is null");
     VTMC_HIP(ctx, hipSetDevice(ctx->device));
@@ -485,7 +596,7 @@ int32_t vtmc_read_cases(vtmc_ctx *ctx, uint8_t *dst, int64_t capacity)
     if (int rc = ensure(ctx, ctx->cases, (size_t)need)) return rc;
     DevBuf tmp;
     if (int rc = ensure(ctx, tmp, sizeof(uint32_t) * (size_t)ctx->last_blocks)) return rc;
-    hipError_t e = launch_classify_blocks(ctx->last_space, ctx->tables, (uint32_t *)tmp.p, (uint8_t *)ctx->cases.p, ctx->n_cus, ctx->stream);
+    hipError_t e = launch_classify_blocks(ctx->last_space, ctx->tables, (uint32_t *)tmp.p, (uint8_t *)ctx->cases.p, nullptr, ctx->n_cus, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(dst, ctx->cases.p, (size_t)need, hipMemcpyDeviceToHost);
     release(tmp);

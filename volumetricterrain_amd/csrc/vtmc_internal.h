@@ -78,15 +78,20 @@ constexpr int kScanTile = 2048;  // block counts per scan workgroup (256 threads
 
 // Launch wrappers (mc_kernels.hip).  All asynchronous on `stream`; return hipGetLastError().
 hipError_t launch_classify_blocks(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
-                                  uint8_t *cases_or_null, int n_cus, hipStream_t stream);
+                                  uint8_t *cases_or_null, uint32_t *vcounts_or_null, int n_cus, hipStream_t stream);
 hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
-                                 int ablate, hipStream_t stream);
+                                 uint32_t *vcounts_or_null, int ablate, hipStream_t stream);
 hipError_t launch_scan(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list,
                        uint32_t *partials, uint32_t *totals, int bpv, int n_volumes,
                        uint32_t *volume_counts, hipStream_t stream);
 hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets,
                        const int32_t *active_list, const uint32_t *totals, uint32_t capacity,
                        void *triangles, int n_cus, const Tuning &tune, unsigned *queue, hipStream_t stream);
+
+hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets, const uint32_t *voffsets,
+                               const int32_t *active_list, const uint32_t *totals, const uint32_t *vtotals, uint32_t tri_capacity,
+                               uint32_t vert_capacity, void *vertices, void *indices, int n_cus, const Tuning &tune, unsigned *queue,
+                               hipStream_t stream);
 
 // sweep_kernels.hip: single-pass classify + chained scan + emit for dense volumes with stride_x == 1.
 // `scratch` holds sweep_scratch_bytes(sp) bytes; offsets gets n_blocks + 1 entries; T lands in

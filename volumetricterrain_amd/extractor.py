@@ -10,7 +10,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import TRI_DTYPE, DensityParams, Modifier, VolumeBatch, VtmcError
+from ._lib import TRI_DTYPE, VERTEX_DTYPE, DensityParams, Modifier, VolumeBatch, VtmcError
 
 
 def _ptr(a):
@@ -110,6 +110,28 @@ class Extractor:
         offs = np.zeros(n_blocks + 1, np.int32) if with_offsets else None
         self._check(self._L.vtmc_read_triangles(self._h, _ptr(tris), n_tris, _ptr(offs)))
         return (tris, offs) if with_offsets else tris
+
+    # -- indexed (welded) output ---------------------------------------------------------------
+    def set_output_mode(self, indexed):
+        """indexed=True: the following extract_* / terrain_update calls produce vtmc_vertex + index
+        buffers (read_indexed_mesh) instead of 76-byte records (read_triangles)."""
+        self._check(self._L.vtmc_set_output_mode(self._h, 1 if indexed else 0))
+
+    def read_indexed_mesh(self):
+        """(vertices[V], indices[T,3] block-local, block_vertex_offsets[B+1], block_tri_offsets[B+1])."""
+        n_blocks, n_tris = self.last_counts()
+        nv = ctypes.c_int32()
+        self._check(self._L.vtmc_last_vertex_count(self._h, ctypes.byref(nv)))
+        verts = np.zeros(nv.value, VERTEX_DTYPE)
+        idx = np.zeros((n_tris, 3), np.int32)
+        voffs, toffs = np.zeros(n_blocks + 1, np.int32), np.zeros(n_blocks + 1, np.int32)
+        self._check(self._L.vtmc_read_indexed_mesh(self._h, _ptr(verts), nv.value, _ptr(idx), n_tris, _ptr(voffs), _ptr(toffs)))
+        return verts, idx, voffs, toffs
+
+    def device_indexed_results(self):
+        a, b, c, d = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self._L.vtmc_device_indexed_results(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)))
+        return a.value, b.value, c.value, d.value
 
     def read_cases(self):
         n_blocks, _ = self.last_counts()
