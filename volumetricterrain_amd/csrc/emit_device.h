@@ -249,6 +249,7 @@ __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_v
 // t' = 1 - t differs from this one by rounding only (<= ~1e-6 in cell units, bar 1e-5).
 // ----------------------------------------------------------------------------------------------
 constexpr int kVertDwords = 6;  // 24-byte vertex record
+constexpr int kVlistCap = 448;  // queued vertices before a flush (a 64-point step adds at most 192)
 
 struct __attribute__((aligned(16))) EmitLdsIdx {
     float tile[1000];
@@ -256,7 +257,7 @@ struct __attribute__((aligned(16))) EmitLdsIdx {
     unsigned short acell[512];      // active cells of the block, ascending cell id
     unsigned char cases[512];
     unsigned short vmap[736];       // lattice point -> first vertex id | axis flags << 12
-    unsigned short vlist[192];      // vertices of the current 64-point step: point << 2 | axis
+    unsigned short vlist[kVlistCap];  // vertices waiting to be evaluated: point << 2 | axis
     float stage[64 * kVertDwords + 4];
 };
 static_assert(sizeof(EmitLdsIdx) % 16 == 0 && offsetof(EmitLdsIdx, stage) % 16 == 0, "stage must stay 16-byte aligned");
@@ -299,33 +300,17 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
         n_act += __builtin_popcountll(m);
     }
 
-    // vertices: number the sign-change edges 64 lattice points at a time and emit them at once
-    int vrun = 0;
-    for (int p0 = 0; p0 < 729; p0 += 64) {
-        const int p = p0 + lane;
-        unsigned flags = 0;
-        if (p < 729) {
-            const int x = p % 9, y = (p / 9) % 9, z = p / 81;
-            const float *q = tile + x + 10 * y + 100 * z;
-            const bool s0 = q[0] > 0.f;
-            flags = (unsigned)(x < 8 && s0 != (q[1] > 0.f)) | ((unsigned)(y < 8 && s0 != (q[10] > 0.f)) << 1) |
-                    ((unsigned)(z < 8 && s0 != (q[100] > 0.f)) << 2);
-        }
-        unsigned step_total;
-        const unsigned pre = wave_prefix3((unsigned)__builtin_popcount(flags), step_total);
-        if (p < 729) L->vmap[p] = (unsigned short)((unsigned)(vrun + (int)pre) | (flags << 12));
-        {
-            unsigned k = pre;
-#pragma unroll
-            for (unsigned a = 0; a < 3; ++a)
-                if (flags & (1u << a)) L->vlist[k++] = (unsigned short)(((unsigned)p << 2) | a);
-        }
+    // vertices: number the sign-change edges 64 lattice points at a time; their (point, axis) entries
+    // queue up in vlist and are evaluated 64 per step, one lane per vertex
+    int vrun = 0;    // vertices numbered so far
+    int vdone = 0;   // vertices already written out
+    auto flush_vertices = [&]() {
         VTMC_WAVE_SYNC();
-        int n_v = (int)step_total;
-        if (vrun + n_v > vert_budget) n_v = vert_budget - vrun > 0 ? vert_budget - vrun : 0;  // never outside the block's slice
+        int n_v = vrun - vdone;
+        if (vdone + n_v > vert_budget) n_v = vert_budget - vdone > 0 ? vert_budget - vdone : 0;  // never outside the block's slice
         for (int s0 = 0; s0 < n_v; s0 += 64) {
             const int s = s0 + lane;
-            const size_t d0 = (vert_base + (size_t)(vrun + s0)) * kVertDwords;
+            const size_t d0 = (vert_base + (size_t)(vdone + s0)) * kVertDwords;
             const int sh = (int)(d0 & 3);
             if (s < n_v) {
                 const unsigned ent = L->vlist[s];
@@ -357,8 +342,29 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
             stream_out_staged(L->stage, out_vertices, d0, sh, cnt * kVertDwords, lane);
             VTMC_WAVE_SYNC();
         }
+        vdone = vrun;
+    };
+    for (int p0 = 0; p0 < 729; p0 += 64) {
+        if (vrun - vdone > kVlistCap - 192) flush_vertices();  // wave-uniform: the next step may add 192
+        const int p = p0 + lane;
+        unsigned flags = 0;
+        if (p < 729) {
+            const int x = p % 9, y = (p / 9) % 9, z = p / 81;
+            const float *q = tile + x + 10 * y + 100 * z;
+            const bool s0 = q[0] > 0.f;
+            flags = (unsigned)(x < 8 && s0 != (q[1] > 0.f)) | ((unsigned)(y < 8 && s0 != (q[10] > 0.f)) << 1) |
+                    ((unsigned)(z < 8 && s0 != (q[100] > 0.f)) << 2);
+        }
+        unsigned step_total;
+        const unsigned pre = wave_prefix3((unsigned)__builtin_popcount(flags), step_total);
+        if (p < 729) L->vmap[p] = (unsigned short)((unsigned)(vrun + (int)pre) | (flags << 12));
+        unsigned k = (unsigned)(vrun - vdone) + pre;
+#pragma unroll
+        for (unsigned a = 0; a < 3; ++a)
+            if (flags & (1u << a)) L->vlist[k++] = (unsigned short)(((unsigned)p << 2) | a);
         vrun += (int)step_total;
     }
+    flush_vertices();
 
     // pass 2 + index flush: triangle slots, 64 active cells per step
     auto flush = [&](int pending, size_t base) {
