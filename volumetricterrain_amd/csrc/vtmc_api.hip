@@ -110,74 +110,44 @@ void release(DevBuf &b)
     b.bytes = 0;
 }
 
-// classify -> scan -> emit on `stream`; fills last_* and stage_ms.
-int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t flags, hipStream_t stream,
-                 int64_t *tri_count)
+// Single pass: classify + chained scan + emit in one kernel (sweep_kernels.hip).  The kernel counts
+// every triangle but writes only those below the buffer's capacity, so a buffer that turns out too
+// small costs one more launch (the first call on a new field, typically).
+int run_sweep(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, hipStream_t stream, int64_t &T_found)
 {
-    BlockSpace sp = sp_in;
-    const int B = sp.n_blocks;
-    ctx->has_result = false;
-    if (B == 0) {
-        ctx->has_result = true;
-        ctx->last_space = sp;
-        ctx->last_blocks = 0;
-        ctx->last_volumes = n_volumes;
-        ctx->last_tris = 0;
-        ctx->last_verts = 0;
-        ctx->last_indexed = ctx->output_mode == VTMC_OUTPUT_INDEXED;
-        if (ctx->last_indexed) {
-            if (int rc = ensure(ctx, ctx->voffsets, sizeof(uint32_t))) return rc;
-            VTMC_HIP(ctx, hipMemsetAsync(ctx->voffsets.p, 0, sizeof(uint32_t), stream));
-        }
-        memset(ctx->stage_ms, 0, sizeof ctx->stage_ms);
-        if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t))) return rc;
-        VTMC_HIP(ctx, hipMemsetAsync(ctx->offsets.p, 0, sizeof(uint32_t), stream));
+    if (int rc = ensure(ctx, ctx->sweep, sweep_scratch_bytes(sp))) return rc;
+    for (int attempt = 0;; ++attempt) {
+        const size_t cap = std::min<size_t>(ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
+        VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
+        VTMC_HIP(ctx, launch_sweep(sp, ctx->tables, ctx->sweep.p, (uint32_t *)ctx->offsets.p, cap, ctx->tris.p, ctx->n_cus, n_volumes,
+                                   (uint32_t *)ctx->volcounts.p, ctx->tune, stream));
+        VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
+        VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->sweep.p, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         VTMC_HIP(ctx, hipStreamSynchronize(stream));
-        if (tri_count) *tri_count = 0;
-        return VTMC_OK;
+        if (ctx->h_totals[kCtrlError])
+            return fail(ctx, VTMC_ERR_DEVICE, "sweep kernel: a chained-scan wait timed out (predecessor brick never published)");
+        const uint64_t T = ((uint64_t)ctx->h_totals[kCtrlTotalHi] << 32) | ctx->h_totals[kCtrlTotalLo];
+        if (T > 0x7fffffffull) return fail(ctx, VTMC_ERR_TOO_LARGE, "%llu triangles exceed the int32 range of the ABI", (unsigned long long)T);
+        T_found = (int64_t)T;
+        if ((size_t)T <= cap) break;
+        if (attempt == 1) return fail(ctx, VTMC_ERR_DEVICE, "triangle buffer still too small after growing");
+        if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * ((size_t)T + (size_t)T / 8 + 1024))) return rc;
     }
-    // the emit kernel addresses a tile with 32-bit byte offsets from the block origin
-    if ((9.0 * ((double)sp.sx + (double)sp.sy + (double)sp.sz) + 1.0) * 4.0 >= 4294967296.0)
-        return fail(ctx, VTMC_ERR_TOO_LARGE, "strides too large: a 10x10x10 tile must span less than 4 GiB");
-    if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
-    if (int rc = ensure(ctx, ctx->volcounts, sizeof(uint32_t) * 2 * (size_t)std::max(n_volumes, 1))) return rc;
-    if (!ctx->tris.p)
-        if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * ((size_t)1 << 20))) return rc;
+    float ms = 0;
+    VTMC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]));
+    ctx->stage_ms[0] = ctx->stage_ms[3] = ms;
+    ctx->stage_ms[1] = ctx->stage_ms[2] = 0;
+    return VTMC_OK;
+}
 
-    const bool dense = !sp.list && sp.sx == 1 && sp.nx >= 32 && !(flags & (VTMC_FLAG_WANT_CASES | VTMC_FLAG_NO_DENSE_PATH));
-    const bool indexed = ctx->output_mode == VTMC_OUTPUT_INDEXED;
-    int64_t T_found = 0, V_found = 0;
-
-    if (dense && ctx->tune.sweep && !indexed) {
-        // single pass: classify + chained scan + emit in one kernel (sweep_kernels.hip).  The kernel
-        // counts every triangle but writes only those below the buffer's capacity, so a buffer that
-        // turns out too small costs one more launch (the first call on a new field, typically).
-        if (int rc = ensure(ctx, ctx->sweep, sweep_scratch_bytes(sp))) return rc;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            const size_t cap = std::min<size_t>(ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
-            VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
-            VTMC_HIP(ctx, launch_sweep(sp, ctx->tables, ctx->sweep.p, (uint32_t *)ctx->offsets.p, cap, ctx->tris.p, ctx->n_cus,
-                                       n_volumes, (uint32_t *)ctx->volcounts.p, ctx->tune, stream));
-            VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
-            VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->sweep.p, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            VTMC_HIP(ctx, hipStreamSynchronize(stream));
-            if (ctx->h_totals[kCtrlError])
-                return fail(ctx, VTMC_ERR_DEVICE, "sweep kernel: a chained-scan wait timed out (predecessor brick never published)");
-            const uint64_t T = ((uint64_t)ctx->h_totals[kCtrlTotalHi] << 32) | ctx->h_totals[kCtrlTotalLo];
-            if (T > 0x7fffffffull) return fail(ctx, VTMC_ERR_TOO_LARGE, "%llu triangles exceed the int32 range of the ABI", (unsigned long long)T);
-            T_found = (int64_t)T;
-            if ((size_t)T <= cap) break;
-            if (attempt == 1) return fail(ctx, VTMC_ERR_DEVICE, "triangle buffer still too small after growing");
-            const size_t want = (size_t)T + (size_t)T / 8 + 1024;
-            if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * want)) return rc;
-        }
-        float ms = 0;
-        VTMC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]));
-        ctx->stage_ms[0] = ms;
-        ctx->stage_ms[1] = 0;
-        ctx->stage_ms[2] = 0;
-        ctx->stage_ms[3] = ms;
-    } else {
+// classify -> scan -> emit as separate kernels; `indexed` selects the welded output.  {T, nActive}
+// (and V) stay in device memory until the single read-back at the end; the emit kernel refuses to
+// run past its buffers' capacity, in which case they are grown (with head-room, so a slowly changing
+// field does not regrow every frame) and only the emit stage is queued again.
+int run_staged(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t flags, bool dense, bool indexed, hipStream_t stream,
+               int64_t &T_found, int64_t &V_found)
+{
+    const int B = sp.n_blocks;
     const int n_tiles = (B + kScanTile - 1) / kScanTile;
     if (int rc = ensure(ctx, ctx->counts, sizeof(uint32_t) * (size_t)B)) return rc;
     if (int rc = ensure(ctx, ctx->active, sizeof(int32_t) * (size_t)B)) return rc;
@@ -188,7 +158,6 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
         if (int rc = ensure(ctx, ctx->cases, (size_t)B * 512)) return rc;
         d_cases = (uint8_t *)ctx->cases.p;
     }
-
     uint32_t *d_vcounts = nullptr;
     if (indexed) {
         if (int rc = ensure(ctx, ctx->vcounts, sizeof(uint32_t) * (size_t)B)) return rc;
@@ -206,59 +175,42 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
     if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_vcounts, ctx->tune.classify_ablate, stream));
     else VTMC_HIP(ctx, launch_classify_blocks(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_cases, d_vcounts, ctx->n_cus, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
-    VTMC_HIP(ctx, launch_scan((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p,
-                              (int32_t *)ctx->active.p, (uint32_t *)ctx->partials.p, (uint32_t *)ctx->totals.p,
-                              sp.bpv, n_volumes, (uint32_t *)ctx->volcounts.p, stream));
+    VTMC_HIP(ctx, launch_scan((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p, (int32_t *)ctx->active.p,
+                              (uint32_t *)ctx->partials.p, (uint32_t *)ctx->totals.p, sp.bpv, n_volumes, (uint32_t *)ctx->volcounts.p, stream));
     if (indexed)  // the same scan over the welded-vertex counts: per-block vertex offsets + V
         VTMC_HIP(ctx, launch_scan(d_vcounts, B, (uint32_t *)ctx->voffsets.p, nullptr, (uint32_t *)ctx->vpartials.p,
                                   (uint32_t *)ctx->vtotals.p, sp.bpv, 0, nullptr, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
 
-    if (indexed) {
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            const size_t tcap = std::min<size_t>(ctx->indices.bytes / (3 * sizeof(int32_t)), 0x7fffffffu);
-            const size_t vcap = std::min<size_t>(ctx->verts.bytes / sizeof(vtmc_vertex), 0x7fffffffu);
-            uint32_t *queue = (uint32_t *)ctx->totals.p + 64;
-            VTMC_HIP(ctx, hipMemsetAsync(queue, 0, kQueueWords * sizeof(uint32_t), stream));
-            VTMC_HIP(ctx, launch_emit_indexed(sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const uint32_t *)ctx->voffsets.p,
-                                              (const int32_t *)ctx->active.p, (const uint32_t *)ctx->totals.p,
-                                              (const uint32_t *)ctx->vtotals.p, (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p,
-                                              ctx->indices.p, ctx->n_cus, ctx->tune, queue, stream));
-            VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
-            VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->totals.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 2, ctx->vtotals.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            VTMC_HIP(ctx, hipStreamSynchronize(stream));
-            const uint32_t T = ctx->h_totals[0], V = ctx->h_totals[2];
-            if (T > 0x7fffffffu || V > 0x7fffffffu) return fail(ctx, VTMC_ERR_TOO_LARGE, "%u triangles / %u vertices exceed the int32 range of the ABI", T, V);
-            T_found = T;
-            V_found = V;
-            if ((size_t)T <= tcap && (size_t)V <= vcap) break;
-            if (attempt == 1) return fail(ctx, VTMC_ERR_DEVICE, "indexed buffers still too small after growing");
-            if ((size_t)T > tcap)
-                if (int rc = ensure(ctx, ctx->indices, sizeof(int32_t) * 3 * ((size_t)T + (size_t)T / 8 + 1024))) return rc;
-            if ((size_t)V > vcap)
-                if (int rc = ensure(ctx, ctx->verts, sizeof(vtmc_vertex) * ((size_t)V + (size_t)V / 8 + 1024))) return rc;
-            VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
-        }
-    } else
-
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        const size_t cap = std::min<size_t>(ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
+    for (int attempt = 0;; ++attempt) {
+        const size_t tcap = std::min<size_t>(indexed ? ctx->indices.bytes / (3 * sizeof(int32_t)) : ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
+        const size_t vcap = indexed ? std::min<size_t>(ctx->verts.bytes / sizeof(vtmc_vertex), 0x7fffffffu) : 0;
         uint32_t *queue = (uint32_t *)ctx->totals.p + 64;
         VTMC_HIP(ctx, hipMemsetAsync(queue, 0, kQueueWords * sizeof(uint32_t), stream));
-        VTMC_HIP(ctx, launch_emit(sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const int32_t *)ctx->active.p,
-                                  (const uint32_t *)ctx->totals.p, (uint32_t)cap, ctx->tris.p, ctx->n_cus, ctx->tune, queue, stream));
+        if (indexed)
+            VTMC_HIP(ctx, launch_emit_indexed(sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const uint32_t *)ctx->voffsets.p,
+                                              (const int32_t *)ctx->active.p, (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->vtotals.p,
+                                              (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p, ctx->indices.p, ctx->n_cus, ctx->tune, queue, stream));
+        else
+            VTMC_HIP(ctx, launch_emit(sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const int32_t *)ctx->active.p,
+                                      (const uint32_t *)ctx->totals.p, (uint32_t)tcap, ctx->tris.p, ctx->n_cus, ctx->tune, queue, stream));
         VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
         VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->totals.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (indexed) VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 2, ctx->vtotals.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         VTMC_HIP(ctx, hipStreamSynchronize(stream));
-        const uint32_t T = ctx->h_totals[0];
-        if (T > 0x7fffffffu) return fail(ctx, VTMC_ERR_TOO_LARGE, "%u triangles exceed the int32 range of the ABI", T);
+        const uint32_t T = ctx->h_totals[0], V = indexed ? ctx->h_totals[2] : 0u;
+        if (T > 0x7fffffffu || V > 0x7fffffffu)
+            return fail(ctx, VTMC_ERR_TOO_LARGE, "%u triangles / %u vertices exceed the int32 range of the ABI", T, V);
         T_found = T;
-        if ((size_t)T <= cap) break;
-        if (attempt == 1) return fail(ctx, VTMC_ERR_DEVICE, "triangle buffer still too small after growing");
-        // grow (with head-room so a slowly changing field does not regrow every frame) and redo the emit stage
-        size_t want = (size_t)T + (size_t)T / 8 + 1024;
-        if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * want)) return rc;
+        V_found = V;
+        if ((size_t)T <= tcap && (size_t)V <= vcap) break;
+        if (attempt == 1) return fail(ctx, VTMC_ERR_DEVICE, "output buffers still too small after growing");
+        if ((size_t)T > tcap) {
+            const size_t want = (size_t)T + (size_t)T / 8 + 1024;
+            if (int rc = indexed ? ensure(ctx, ctx->indices, sizeof(int32_t) * 3 * want) : ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * want)) return rc;
+        }
+        if ((size_t)V > vcap)
+            if (int rc = ensure(ctx, ctx->verts, sizeof(vtmc_vertex) * ((size_t)V + (size_t)V / 8 + 1024))) return rc;
         VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
     }
     float a = 0, b = 0, c = 0;
@@ -269,8 +221,40 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
     ctx->stage_ms[1] = b;
     ctx->stage_ms[2] = c;
     ctx->stage_ms[3] = a + b + c;
-    }
+    return VTMC_OK;
+}
 
+// The device side of BatchUpdate (VoxelTerrain.cs:365-427) on `stream`; fills last_* and stage_ms.
+int extract_core(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t flags, hipStream_t stream, int64_t *tri_count)
+{
+    const int B = sp.n_blocks;
+    const bool indexed = ctx->output_mode == VTMC_OUTPUT_INDEXED;
+    ctx->has_result = false;
+    int64_t T_found = 0, V_found = 0;
+    if (B == 0) {  // the reference's early exit (VoxelTerrain.cs:396-405): empty offsets, nothing launched
+        memset(ctx->stage_ms, 0, sizeof ctx->stage_ms);
+        if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t))) return rc;
+        VTMC_HIP(ctx, hipMemsetAsync(ctx->offsets.p, 0, sizeof(uint32_t), stream));
+        if (indexed) {
+            if (int rc = ensure(ctx, ctx->voffsets, sizeof(uint32_t))) return rc;
+            VTMC_HIP(ctx, hipMemsetAsync(ctx->voffsets.p, 0, sizeof(uint32_t), stream));
+        }
+        VTMC_HIP(ctx, hipStreamSynchronize(stream));
+    } else {
+        // the emit kernel addresses a tile with 32-bit byte offsets from the block origin
+        if ((9.0 * ((double)sp.sx + (double)sp.sy + (double)sp.sz) + 1.0) * 4.0 >= 4294967296.0)
+            return fail(ctx, VTMC_ERR_TOO_LARGE, "strides too large: a 10x10x10 tile must span less than 4 GiB");
+        if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
+        if (int rc = ensure(ctx, ctx->volcounts, sizeof(uint32_t) * 2 * (size_t)std::max(n_volumes, 1))) return rc;
+        if (!indexed && !ctx->tris.p)
+            if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * ((size_t)1 << 20))) return rc;
+        const bool dense = !sp.list && sp.sx == 1 && sp.nx >= 32 && !(flags & (VTMC_FLAG_WANT_CASES | VTMC_FLAG_NO_DENSE_PATH));
+        if (dense && ctx->tune.sweep && !indexed) {
+            if (int rc = run_sweep(ctx, sp, n_volumes, stream, T_found)) return rc;
+        } else {
+            if (int rc = run_staged(ctx, sp, n_volumes, flags, dense, indexed, stream, T_found, V_found)) return rc;
+        }
+    }
     ctx->has_result = true;
     ctx->last_space = sp;
     ctx->last_blocks = B;
@@ -278,7 +262,7 @@ int extract_core(vtmc_ctx *ctx, const BlockSpace &sp_in, int n_volumes, uint32_t
     ctx->last_tris = T_found;
     ctx->last_verts = V_found;
     ctx->last_indexed = indexed;
-    if (tri_count) *tri_count = ctx->last_tris;
+    if (tri_count) *tri_count = T_found;
     return VTMC_OK;
 }
 
