@@ -228,7 +228,7 @@ def main():
                 "frac_of_peak": round(path_bytes / (avg["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "read_only_frac_of_peak": round(4.0 * samples / (avg["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             cpu = cpu_baseline(d_field, dim, c, min(args.cpu_sample_chunks, n_chunks), args.kind)
         out = {
             "metric": "marching-cubes extraction throughput on a %d^3 %s grid per GPU (Mvoxels/s)" % (n, args.kind),

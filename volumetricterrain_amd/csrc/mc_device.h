@@ -114,7 +114,8 @@ __device__ __forceinline__ unsigned classify_brick_column(const BlockSpace &sp, 
         for (int yy = 0; yy < 9; ++yy) {
             // diagnostics only (ablate & 1): alias the halo rows to their neighbours, i.e. no halo traffic
             const int y2 = (ablate & 1) && yy == 8 ? 7 : yy, z2 = (ablate & 1) && zz == 8 ? 7 : zz;
-            val[zz][yy] = brick_base[gxc + y2 * sp.sy + z2 * sp.sz];
+            const float *src = brick_base + gxc + y2 * sp.sy + z2 * sp.sz;
+            val[zz][yy] = (ablate & 2) ? __builtin_nontemporal_load(src) : *src;  // diagnostics: streaming-hint loads
         }
     // 65th column: row r = zz*9 + yy is read by lane r (two passes cover 81 rows)
     float ex0, ex1;
