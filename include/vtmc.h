@@ -217,6 +217,9 @@ int32_t vtmc_device_indexed_results(vtmc_ctx *ctx, const vtmc_vertex **d_vertice
 #define VTMC_MOD_SPHERE 1    /* TerrainModifier.cs:70-91   f = _radius - |pos - c|    p[0..2] = _center, p[3] = _radius */
 #define VTMC_MOD_CYLINDER 2  /* TerrainModifier.cs:96-152  p[0..2] = _axisStart, p[3..5] = _axisDir (normalised),
                                                            p[6] = _axisLength, p[7] = _radius */
+#define VTMC_MOD_HEIGHTMAP 3 /* IslandModifier.cs:34-73    f = bilinear(_heightmap)(x, z) - y; p[0] = _island.width,
+                                                           p[1] = _island.height; data = _heightmap (host pointer,
+                                                           float[data_dims[0], data_dims[1]] row-major as the C# float[,]) */
 
 /* One queued TerrainModifier (TerrainModifier.cs:19-33).  lower / upper are the values the C#
  * LowerBound / UpperBound properties return (world space): the shim copies them, so Unity's
@@ -227,6 +230,8 @@ typedef struct vtmc_modifier {
     float lower[3];
     float upper[3];
     float p[8];
+    const float *data;    /* VTMC_MOD_HEIGHTMAP only: borrowed for the call, copied to the device */
+    int32_t data_dims[2];
 } vtmc_modifier;
 
 /* Replaces the grid allocation + fill of VoxelTerrain.Init (VoxelTerrain.cs:121-149): a

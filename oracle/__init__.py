@@ -23,7 +23,8 @@ assert TRI_DTYPE.itemsize == 76  # VoxelTerrain.cs:36
 class Modifier(ctypes.Structure):
     """TerrainModifier.cs:19-33 flattened (same layout as vtmc_modifier of include/vtmc.h)."""
     _fields_ = [("kind", ctypes.c_int32), ("add_or_erode", ctypes.c_int32), ("lower", ctypes.c_float * 3),
-                ("upper", ctypes.c_float * 3), ("p", ctypes.c_float * 8)]
+                ("upper", ctypes.c_float * 3), ("p", ctypes.c_float * 8), ("data", ctypes.c_void_p),
+                ("dims", ctypes.c_int32 * 2)]
 
 
 class DensityParams(ctypes.Structure):
@@ -296,10 +297,24 @@ def cylinder_modifier(start, direction, length, radius, add=True):
     return m
 
 
+def heightmap_modifier(heightmap, island_width, island_height, max_elevation, add=True):
+    """IslandModifier (IslandModifier.cs:34-92): bounds (0, float.MinValue, 0) .. (_island.width, _maxElevation, _island.height)."""
+    hm = np.ascontiguousarray(heightmap, np.float32)
+    m = Modifier(3, int(add))
+    m.lower[:] = (0.0, FLT_LOWEST, 0.0)
+    m.upper[:] = (island_width, max_elevation, island_height)
+    m.p[0:2] = (island_width, island_height)
+    m.data = hm.ctypes.data
+    m.dims[:] = hm.shape
+    m._keep = hm   # keeps the array alive as long as the struct
+    return m
+
+
 def modifier_array(mods):
     arr = (Modifier * max(len(mods), 1))()
     for i, m in enumerate(mods):
         arr[i] = m
+    arr._keep = list(mods)   # heightmaps referenced by pointer stay alive
     return arr
 
 

@@ -11,6 +11,7 @@
  *                             erode = Clamp(Min(S, -Clamp(Q, void, full)), void, full)
  *   VoxelTerrain.cs:307-317   dirty blocks: up >= 8b && low <= 8b + 8 on every axis (the literal triple loop)
  *   TerrainModifier.cs:59-62, :79-82, :143-149   QueryDensity of plane, sphere, cylinder
+ *   IslandModifier.cs:45-73   QueryDensity of the heightmap modifier (bilinear, Mathf.Lerp clamps t)
  *
  * PARITY STATUS: unpinned against an execution of the reference for the clamp values only:
  * voidDensity / fullDensity are UnityEngine.Random draws on every read (VoxelTerrain.cs:50-51), a
@@ -28,7 +29,10 @@ typedef struct {
     int32_t add_or_erode; /* TerrainModifier.AddOrErode */
     float lower[3];       /* LowerBound */
     float upper[3];       /* UpperBound */
-    float p[8];           /* plane: _height; sphere: _center, _radius; cylinder: _axisStart, _axisDir, _axisLength, _radius */
+    float p[8];           /* plane: _height; sphere: _center, _radius; cylinder: _axisStart, _axisDir, _axisLength, _radius;
+                             heightmap: _island.width, _island.height */
+    const float *data;    /* heightmap: _heightmap, float[dims[0], dims[1]] row-major (C# float[,]) */
+    int32_t dims[2];
 } vto_modifier;
 
 static float uniform01(uint64_t seed, uint32_t event, uint64_t sample, uint32_t draw)
@@ -47,8 +51,29 @@ static float clampf(float v, float lo, float hi) /* Mathf.Clamp */
     return v;
 }
 
+static float lerp_unity(float a, float b, float t) /* Mathf.Lerp */
+{
+    t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+    return a + (b - a) * t;
+}
+
 static float query_density(const vto_modifier *m, float px, float py, float pz)
 {
+    if (m->kind == 3) { /* IslandModifier.cs:45-73 */
+        const float wm1 = (float)(m->dims[0] - 1), hm1 = (float)(m->dims[1] - 1);
+        float u = clampf(px, 0.0f, m->p[0]);
+        u = u / m->p[0] * wm1;
+        u = clampf(u, 0.0f, wm1);
+        float v = clampf(pz, 0.0f, m->p[1]);
+        v = v / m->p[1] * hm1;
+        v = clampf(v, 0.0f, hm1);
+        const int u0 = (int)floorf(u), u1 = (int)ceilf(u), v0 = (int)floorf(v), v1 = (int)ceilf(v);
+        const float h00 = m->data[(size_t)u0 * m->dims[1] + v0], h10 = m->data[(size_t)u1 * m->dims[1] + v0];
+        const float h01 = m->data[(size_t)u0 * m->dims[1] + v1], h11 = m->data[(size_t)u1 * m->dims[1] + v1];
+        const float h0 = lerp_unity(h00, h01, v - (float)v0);
+        const float h1 = lerp_unity(h10, h11, v - (float)v0);
+        return lerp_unity(h0, h1, u - (float)u0) - py;
+    }
     if (m->kind == 0) return m->p[0] - py; /* TerrainModifier.cs:59-62 */
     if (m->kind == 1) {                    /* TerrainModifier.cs:79-82 */
         float dx = px - m->p[0], dy = py - m->p[1], dz = pz - m->p[2];

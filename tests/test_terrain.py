@@ -19,16 +19,24 @@ SPECS = [
 ]
 
 
+def island_heightmap(res=(48, 40)):
+    """A smooth synthetic island: what Island.GetElevation would have filled in (IslandModifier.cs:85-91)."""
+    u = np.linspace(-1, 1, res[0], dtype=np.float32)[:, None]
+    v = np.linspace(-1, 1, res[1], dtype=np.float32)[None, :]
+    return (14.0 * np.exp(-2.5 * (u * u + v * v)) + 1.5 * np.sin(5 * u) * np.cos(4 * v) + 3.0).astype(np.float32)
+
+
 def build(spec):
     kind, args = spec
-    return {"plane": vt.PlaneModifier, "sphere": vt.SphereModifier, "cylinder": vt.CylinderModifier}[kind](*args)
+    return {"plane": vt.PlaneModifier, "sphere": vt.SphereModifier, "cylinder": vt.CylinderModifier,
+            "island": vt.IslandModifier}[kind](*args)
 
 
 def build_oracle(oracle_mod, spec):
     """The same modifier through the oracle's own (independent) bound formulas."""
     kind, args = spec
     return {"plane": oracle_mod.plane_modifier, "sphere": oracle_mod.sphere_modifier,
-            "cylinder": oracle_mod.cylinder_modifier}[kind](*args)
+            "cylinder": oracle_mod.cylinder_modifier, "island": oracle_mod.heightmap_modifier}[kind](*args)
 
 
 def queue():
@@ -162,3 +170,44 @@ def test_gpu_terrain_errors():
         with pytest.raises(vt.VtmcError) as e:
             ex.terrain_init(1032, 16, 16)
         assert e.value.code == -2 and "too high resolution" in str(e.value)        # VoxelTerrain.cs:141-142
+
+
+def test_oracle_heightmap_modifier_known_answer(oracle_mod):
+    """A flat heightmap of height h is a plane; a ramp along u is reproduced exactly at the heightmap's
+    own sample positions (IslandModifier.cs:45-73)."""
+    t = oracle_mod.Terrain(32, 16, 32, seed=2)
+    t.update([oracle_mod.heightmap_modifier(np.full((5, 7), 6.25, np.float32), 32.0, 32.0, 10.0)])
+    y = np.arange(18, dtype=np.float32)
+    near = np.abs(np.float32(6.25) - y) < 1
+    assert np.array_equal(t.grid[9, :, 20][near], (np.float32(6.25) - y)[near])
+    ramp = np.linspace(2.0, 10.0, 33, dtype=np.float32)[:, None].repeat(4, 1)   # heightmap sample i sits at x = i
+    t2 = oracle_mod.Terrain(32, 16, 32, seed=2)
+    t2.update([oracle_mod.heightmap_modifier(ramp, 32.0, 32.0, 12.0)])
+    for x in (0, 5, 17, 32):
+        col = t2.grid[x, :, 11]
+        k = int(np.floor(ramp[x, 0]))
+        assert col[k] == ramp[x, 0] - np.float32(k)        # unclamped samples next to the surface are exact
+
+
+@pytest.mark.gpu
+def test_gpu_world_build_with_island_heightmap(oracle_mod):
+    """The reference's world build (TerrainEngine.cs:87-99): IslandModifier first, then river
+    cylinders, one Update.  Grid bit-exact, every block dirty -> dense streaming path."""
+    dims, scale, origin, seed = (64, 32, 64), 1.0, (0.0, 0.0, 0.0), 77
+    hm = island_heightmap()
+    specs = [("island", (hm, 64.0, 64.0, 40.0, True)),
+             ("cylinder", ((8.0, 14.0, 10.0), (1.0, -0.1, 0.6), 40.0, 2.5, False)),
+             ("cylinder", ((30.0, 12.0, 50.0), (0.3, -0.05, -1.0), 35.0, 2.0, False))]
+    with vt.Extractor(0) as ex:
+        ex.terrain_init(*dims, scale, origin, seed)
+        ref = oracle_mod.Terrain(*dims, scale, origin, seed)
+        n_dirty, T = ex.terrain_update([build(s) for s in specs])
+        want_dirty = ref.update(oracle_mods(oracle_mod, specs))
+        assert np.array_equal(ex.terrain_read_samples(), ref.grid)
+        assert n_dirty == len(want_dirty) == 8 * 4 * 8
+        want, want_offs, _ = oracle_mod.extract_grid(ref.grid, want_dirty, threads=8)
+        assert T == len(want) and T > 5000
+        got, offs = ex.read_triangles()
+        assert np.array_equal(offs, want_offs) and np.array_equal(got["block"], want["block"])
+        for f in ("p0", "p1", "p2", "n0", "n1", "n2"):
+            assert np.abs(got[f] - want[f]).max() <= 1e-5

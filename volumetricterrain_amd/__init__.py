@@ -7,6 +7,6 @@ the host-side mirror of the reference's VoxelTerrain chunk API, and chunk shardi
 """
 from ._lib import TRI_DTYPE, VERTEX_DTYPE, VtmcError, load, library_path  # noqa: F401
 from .extractor import Extractor, density_params, elem_strides  # noqa: F401
-from .modifiers import CylinderModifier, PlaneModifier, SphereModifier  # noqa: F401
+from .modifiers import CylinderModifier, IslandModifier, PlaneModifier, SphereModifier  # noqa: F401
 
-__all__ = ["CylinderModifier", "PlaneModifier", "SphereModifier", "Extractor", "TRI_DTYPE", "VERTEX_DTYPE", "VtmcError", "density_params", "elem_strides", "load", "library_path"]
+__all__ = ["CylinderModifier", "IslandModifier", "PlaneModifier", "SphereModifier", "Extractor", "TRI_DTYPE", "VERTEX_DTYPE", "VtmcError", "density_params", "elem_strides", "load", "library_path"]

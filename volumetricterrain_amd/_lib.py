@@ -36,14 +36,15 @@ SYMBOLS = [
     "vtmc_set_output_mode", "vtmc_last_vertex_count", "vtmc_read_indexed_mesh", "vtmc_device_indexed_results",
 ]
 
-MOD_PLANE, MOD_SPHERE, MOD_CYLINDER = 0, 1, 2
+MOD_PLANE, MOD_SPHERE, MOD_CYLINDER, MOD_HEIGHTMAP = 0, 1, 2, 3
 
 
 class Modifier(ctypes.Structure):
     """vtmc_modifier: one queued TerrainModifier (TerrainModifier.cs:19-33), bounds as the C#
     LowerBound / UpperBound properties return them."""
     _fields_ = [("kind", ctypes.c_int32), ("add_or_erode", ctypes.c_int32), ("lower", ctypes.c_float * 3),
-                ("upper", ctypes.c_float * 3), ("p", ctypes.c_float * 8)]
+                ("upper", ctypes.c_float * 3), ("p", ctypes.c_float * 8), ("data", ctypes.c_void_p),
+                ("data_dims", ctypes.c_int32 * 2)]
 
 
 class VolumeBatch(ctypes.Structure):

@@ -4,7 +4,8 @@
 // Replaces (paths relative to /root/reference/Unity-Project/Assets/Scripts/):
 //   VoxelTerrain.cs:145-149  Init: grid filled with "void" values            -> terrain_fill_kernel
 //   VoxelTerrain.cs:284-305  Update: per-sample QueryDensity + clamp + max / min -> terrain_modify_kernel
-//   TerrainModifier.cs:59-62 (plane), :79-82 (sphere), :143-149 (cylinder)  -> query_density
+//   TerrainModifier.cs:59-62 (plane), :79-82 (sphere), :143-149 (cylinder),
+//   IslandModifier.cs:45-73 (bilinear heightmap, the modifier of the world build TerrainEngine.cs:87) -> query_density
 // One lane per sample of the modifier's AABB, x fastest (the grid is x fastest), so a wave reads and
 // writes contiguous 256-byte row segments.  HBM-bound: 8 bytes per touched sample, a handful of
 // FP32 operations in the reference's order (library built with -ffp-contract=off; sqrt is the
@@ -35,8 +36,29 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi)  // Mathf.C
     return v;
 }
 
+__device__ __forceinline__ float lerp_unity(float a, float b, float t)  // Mathf.Lerp: a + (b - a) * Clamp01(t)
+{
+    t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+    return a + (b - a) * t;
+}
+
 __device__ __forceinline__ float query_density(const TerrainModifierArgs &m, float px, float py, float pz)
 {
+    if (m.kind == 3) {  // IslandModifier.cs:45-73: bilinear interpolation of _heightmap[u, v], then elevation - pos.y
+        const float wm1 = (float)(m.dims0 - 1), hm1 = (float)(m.dims1 - 1);
+        float u = clampf(px, 0.0f, m.p[0]);
+        u = u / m.p[0] * wm1;
+        u = clampf(u, 0.0f, wm1);
+        float v = clampf(pz, 0.0f, m.p[1]);
+        v = v / m.p[1] * hm1;
+        v = clampf(v, 0.0f, hm1);
+        const int u0 = (int)floorf(u), u1 = (int)ceilf(u), v0 = (int)floorf(v), v1 = (int)ceilf(v);
+        const float h00 = m.data[(size_t)u0 * m.dims1 + v0], h10 = m.data[(size_t)u1 * m.dims1 + v0];
+        const float h01 = m.data[(size_t)u0 * m.dims1 + v1], h11 = m.data[(size_t)u1 * m.dims1 + v1];
+        const float h0 = lerp_unity(h00, h01, v - (float)v0);
+        const float h1 = lerp_unity(h10, h11, v - (float)v0);
+        return lerp_unity(h0, h1, u - (float)u0) - py;
+    }
     if (m.kind == 0) return m.p[0] - py;  // PlaneModifier: _height - pos.y
     if (m.kind == 1) {                    // SphereModifier: _radius - (pos - _center).magnitude
         const float dx = px - m.p[0], dy = py - m.p[1], dz = pz - m.p[2];

@@ -59,7 +59,7 @@ struct vtmc_ctx {
     int64_t last_tris = 0;
     Tuning tune;
     // device-resident terrain (vtmc_terrain_*)
-    DevBuf terrain;
+    DevBuf terrain, heightmap;
     TerrainShape tshape{};
     bool has_terrain = false;
     uint32_t terrain_events = 0;
@@ -366,7 +366,7 @@ int32_t vtmc_destroy(vtmc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->d_vert, &ctx->d_trinum, &ctx->counts, &ctx->offsets, &ctx->active, &ctx->partials, &ctx->totals,
-                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->sweep, &ctx->terrain,
+                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->sweep, &ctx->terrain, &ctx->heightmap,
                       &ctx->vcounts, &ctx->voffsets, &ctx->vpartials, &ctx->vtotals, &ctx->verts, &ctx->indices})
         release(*b);
     if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
@@ -726,7 +726,9 @@ int32_t vtmc_terrain_update(vtmc_ctx *ctx, const vtmc_modifier *mods, int32_t n_
     };
     for (int32_t i = 0; i < n_mods; ++i) {
         const vtmc_modifier &md = mods[i];
-        if (md.kind < VTMC_MOD_PLANE || md.kind > VTMC_MOD_CYLINDER) return fail(ctx, VTMC_ERR_INVALID_ARG, "modifier %d: unknown kind %d", i, md.kind);
+        if (md.kind < VTMC_MOD_PLANE || md.kind > VTMC_MOD_HEIGHTMAP) return fail(ctx, VTMC_ERR_INVALID_ARG, "modifier %d: unknown kind %d", i, md.kind);
+        if (md.kind == VTMC_MOD_HEIGHTMAP && (!md.data || md.data_dims[0] < 1 || md.data_dims[1] < 1))
+            return fail(ctx, VTMC_ERR_INVALID_ARG, "modifier %d: heightmap data / dims missing", i);
         // world -> sample index: (world - TerrainOrigin) / _voxelScale, floor / ceil, clamp (VoxelTerrain.cs:273-281)
         int low[3], up[3];
         const int top[3] = {W + 1, E + 1, H + 1};
@@ -745,6 +747,17 @@ int32_t vtmc_terrain_update(vtmc_ctx *ctx, const vtmc_modifier *mods, int32_t n_
         a.dy = up[1] - low[1] + 1;
         a.dz = up[2] - low[2] + 1;
         a.event = ++ctx->terrain_events;
+        if (md.kind == VTMC_MOD_HEIGHTMAP && a.dx > 0 && a.dy > 0 && a.dz > 0) {
+            // _heightmap (IslandModifier.cs:36) goes to the device; an earlier modifier of this queue may
+            // still be reading the previous one, hence the drain before the buffer is touched
+            const size_t bytes = sizeof(float) * (size_t)md.data_dims[0] * (size_t)md.data_dims[1];
+            VTMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (int rc = ensure(ctx, ctx->heightmap, bytes)) return rc;
+            VTMC_HIP(ctx, hipMemcpy(ctx->heightmap.p, md.data, bytes, hipMemcpyHostToDevice));
+            a.data = (const float *)ctx->heightmap.p;
+            a.dims0 = md.data_dims[0];
+            a.dims1 = md.data_dims[1];
+        }
         if (a.dx > 0 && a.dy > 0 && a.dz > 0) VTMC_HIP(ctx, launch_terrain_modify((float *)ctx->terrain.p, sh, a, ctx->stream));
         // dirty blocks: up >= 8b && low <= 8b + 8 on every axis (VoxelTerrain.cs:307-317), as index ranges
         int b0[3], b1[3];

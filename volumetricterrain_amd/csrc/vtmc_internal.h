@@ -114,6 +114,8 @@ struct TerrainModifierArgs {
     int lx, ly, lz;          // first sample of the clamped AABB (VoxelTerrain.cs:273-276)
     int dx, dy, dz;          // samples per axis of the AABB, inclusive ends (VoxelTerrain.cs:284-286)
     uint32_t event;          // 1-based index of this modifier application since Init (hash input)
+    const float *data;       // heightmap (device), row-major [dims0][dims1]
+    int dims0, dims1;
 };
 hipError_t launch_terrain_fill(float *grid, long long n, uint64_t seed, int n_cus, hipStream_t stream);
 hipError_t launch_terrain_modify(float *grid, const TerrainShape &sh, const TerrainModifierArgs &m, hipStream_t stream);

@@ -8,7 +8,7 @@ order of the C# expressions.
 """
 import numpy as np
 
-from ._lib import MOD_CYLINDER, MOD_PLANE, MOD_SPHERE, Modifier
+from ._lib import MOD_CYLINDER, MOD_HEIGHTMAP, MOD_PLANE, MOD_SPHERE, Modifier
 
 _f = np.float32
 FLOAT_MIN_VALUE = _f(-3.4028234663852886e38)  # C# float.MinValue
@@ -37,7 +37,11 @@ class TerrainModifier:
         m.upper[:] = tuple(float(x) for x in self.UpperBound)
         p = self.params()
         m.p[0:len(p)] = tuple(float(x) for x in p)
+        self.attach(m)
         return m
+
+    def attach(self, m):
+        """Hook for modifiers that carry an array (the heightmap)."""
 
 
 class PlaneModifier(TerrainModifier):
@@ -115,3 +119,33 @@ class CylinderModifier(TerrainModifier):
 
     def params(self):
         return [*self._axisStart, *self._axisDir, self._axisLength, self._radius]
+
+
+class IslandModifier(TerrainModifier):
+    """The heightmap modifier of the world build (IslandModifier.cs:34-92, inserted at
+    TerrainEngine.cs:87): density = bilinear(_heightmap)(x, z) - y.  The reference fills _heightmap
+    from Island.GetElevation (island generation: out of scope here), so this mirror takes the
+    float[widthRes, heightRes] array itself plus _island.width / .height / ._maxElevation."""
+    kind = MOD_HEIGHTMAP
+
+    def __init__(self, heightmap, island_width, island_height, max_elevation, addOrErode=True):
+        self._heightmap = np.ascontiguousarray(heightmap, _f)
+        if self._heightmap.ndim != 2:
+            raise ValueError("heightmap must be a 2-D array indexed [u, v]")
+        self._width, self._height, self._maxElevation = _f(island_width), _f(island_height), _f(max_elevation)
+        self.AddOrErode = addOrErode
+
+    @property
+    def LowerBound(self):
+        return np.array([0, FLOAT_MIN_VALUE, 0], _f)
+
+    @property
+    def UpperBound(self):
+        return np.array([self._width, self._maxElevation, self._height], _f)
+
+    def params(self):
+        return [self._width, self._height]
+
+    def attach(self, m):
+        m.data = self._heightmap.ctypes.data   # borrowed: this object outlives the call
+        m.data_dims[:] = self._heightmap.shape
