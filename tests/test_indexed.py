@@ -112,3 +112,22 @@ def test_gpu_indexed_config_256(ex, oracle_mod):
         ex.set_output_mode(False)
     assert T == 2655156
     assert (24 * nv + 12 * T) / (76.0 * T) < 0.4                  # < 40 % of the soup's bytes
+
+
+@pytest.mark.gpu
+def test_gpu_indexed_all_256_cases_and_tiles(ex, oracle_mod):
+    """All 256 cube cases (fields.all_cases_tile) through the tile entry point, indexed."""
+    tiles = fields.all_cases_tile()
+    try:
+        ex.set_output_mode(True)
+        T = ex.extract_blocks(tiles)
+        verts, idx, voffs, toffs = ex.read_indexed_mesh()
+    finally:
+        ex.set_output_mode(False)
+    soup, soup_offs, _ = oracle_mod.extract_tiles(tiles)
+    assert T == len(soup) and np.array_equal(toffs, soup_offs)
+    assert len(set(np.unique(oracle_mod.collect_tri_num(tiles)[1]))) == 256       # every case occurs
+    back = oracle_mod.deindex(verts, idx, voffs, toffs)
+    assert np.array_equal(back["block"], soup["block"])
+    for f in FLOATS:
+        assert np.abs(back[f] - soup[f]).max() <= ATOL
