@@ -130,7 +130,11 @@ def main():
     n_chunks = len(origins)
     bpv = (c // 8) ** 3
     ex = vt.Extractor(local)
-    stream = torch.cuda.current_stream()
+    # one explicit (non-default) HIP stream for everything: the library's kernels, the counts copy and
+    # the RCCL all-gather are ordered by it (a NULL handle would mean "the context's own stream" to the
+    # library, which torch's collectives know nothing about)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     prm = vt.density_params(args.kind, n)
 
     # -- setup (untimed): density field generated on the device, chunk by chunk with halos -------
