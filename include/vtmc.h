@@ -144,13 +144,17 @@ int32_t vtmc_copy_volume_counts_device(vtmc_ctx *ctx, uint32_t *d_dst, int32_t c
 int32_t vtmc_reserve_triangles(vtmc_ctx *ctx, int64_t capacity);
 
 /* Per-stage device time of the last extract_* in milliseconds, measured with HIP events on the
- * stream the kernels ran on: ms[0] classify+count, ms[1] scan, ms[2] emit, ms[3] whole call.
+ * stream the kernels ran on: ms[0] classify+count (the whole kernel in sweep mode), ms[1] scan,
+ * ms[2] emit, ms[3] whole call.
  * The reference's only timing hook is the commented-out timer at VoxelTerrain.cs:363/467. */
 int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4]);
 
-/* Diagnostics: select a kernel variant / launch shape for A/B measurements in one process
- * (keys: "emit_version", "emit_fast_math", "emit_wgs_per_cu").  Results stay
- * within the parity bar for every setting; defaults are the shipped configuration. */
+/* Selects a kernel variant / launch shape, mainly for A/B measurements in one process.  Keys that
+ * keep results within the parity bar: "emit_fast_math" (1: v_rcp / v_rsq / fma, default; 0: correctly
+ * rounded, bit-compatible with the CPU oracle), "sweep" (1: the single-pass kernel for dense
+ * x-fastest volumes, default 0), "emit_wgs_per_cu", "sweep_wgs_per_cu", "emit_dynamic",
+ * "emit_sub_log2", "emit_group_log2".  "emit_ablate" / "classify_ablate" switch parts of a kernel
+ * off for diagnosis and make the output INVALID.  Defaults are the shipped configuration. */
 int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value);
 
 /* Synthetic density sampler (the reference has no noise field of its own):

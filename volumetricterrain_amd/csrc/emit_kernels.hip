@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
             b_next = active_list[(ablate & 2) ? ai_begin + (k & 3) : ai_next];
             const char *src = reinterpret_cast<const char *>(sp.base + block_origin(sp, b_next));
 #pragma unroll
-            for (int it = 0; it < 16; ++it) pre[it] = *reinterpret_cast<const float *>(src + toff[it]);
+            for (int it = 0; it < 16; ++it)
+                if (!(ablate & 8) || it < 10) pre[it] = *reinterpret_cast<const float *>(src + toff[it]);  // diagnostics: 62 % of the tile
         }
         request();  // ticket for the block after next; collected at the bottom of this iteration
         VTMC_WAVE_SYNC();
