@@ -36,6 +36,21 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi)  // Mathf.C
     return v;
 }
 
+// Mathf.Clamp(v, voidDensity, fullDensity) with void = draw k, full = draw k+1.  void lies in [-2,-1)
+// and full in [1,2), so a value in [-1,1] is never clamped and neither draw is evaluated for it; the
+// result is the same as drawing both (each draw is a pure function of its counter).
+__device__ __forceinline__ float clamp_drawn(float v, uint64_t seed, uint32_t event, uint64_t sample, uint32_t k)
+{
+    if (v < -1.0f) {
+        const float lo = terrain_uniform(seed, event, sample, k) - 2.0f;
+        if (v < lo) v = lo;
+    } else if (v > 1.0f) {
+        const float hi = terrain_uniform(seed, event, sample, k + 1u) + 1.0f;
+        if (v > hi) v = hi;
+    }
+    return v;
+}
+
 __device__ __forceinline__ float lerp_unity(float a, float b, float t)  // Mathf.Lerp: a + (b - a) * Clamp01(t)
 {
     t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
@@ -44,21 +59,6 @@ __device__ __forceinline__ float lerp_unity(float a, float b, float t)  // Mathf
 
 __device__ __forceinline__ float query_density(const TerrainModifierArgs &m, float px, float py, float pz)
 {
-    if (m.kind == 3) {  // IslandModifier.cs:45-73: bilinear interpolation of _heightmap[u, v], then elevation - pos.y
-        const float wm1 = (float)(m.dims0 - 1), hm1 = (float)(m.dims1 - 1);
-        float u = clampf(px, 0.0f, m.p[0]);
-        u = u / m.p[0] * wm1;
-        u = clampf(u, 0.0f, wm1);
-        float v = clampf(pz, 0.0f, m.p[1]);
-        v = v / m.p[1] * hm1;
-        v = clampf(v, 0.0f, hm1);
-        const int u0 = (int)floorf(u), u1 = (int)ceilf(u), v0 = (int)floorf(v), v1 = (int)ceilf(v);
-        const float h00 = m.data[(size_t)u0 * m.dims1 + v0], h10 = m.data[(size_t)u1 * m.dims1 + v0];
-        const float h01 = m.data[(size_t)u0 * m.dims1 + v1], h11 = m.data[(size_t)u1 * m.dims1 + v1];
-        const float h0 = lerp_unity(h00, h01, v - (float)v0);
-        const float h1 = lerp_unity(h10, h11, v - (float)v0);
-        return lerp_unity(h0, h1, u - (float)u0) - py;
-    }
     if (m.kind == 0) return m.p[0] - py;  // PlaneModifier: _height - pos.y
     if (m.kind == 1) {                    // SphereModifier: _radius - (pos - _center).magnitude
         const float dx = px - m.p[0], dy = py - m.p[1], dz = pz - m.p[2];
@@ -83,31 +83,57 @@ __global__ __launch_bounds__(256) void terrain_fill_kernel(float *__restrict__ g
         grid[i] = terrain_uniform(seed, 0u, (uint64_t)i, 0u) - 2.0f;  // voidDensity
 }
 
-// launch shape: 64 x 4 threads = 4 row segments of 64 samples; grid = (x segments, row quads, z planes)
+// What of a modifier's density does not depend on y (the heightmap's bilinear fetch): evaluated once
+// per (x, z) column and reused for the kYRun samples a thread walks.
+__device__ __forceinline__ float column_term(const TerrainModifierArgs &m, float px, float pz)
+{
+    if (m.kind != 3) return 0.0f;
+    // IslandModifier.cs:45-73: bilinear interpolation of _heightmap[u, v]
+    const float wm1 = (float)(m.dims0 - 1), hm1 = (float)(m.dims1 - 1);
+    float u = clampf(px, 0.0f, m.p[0]);
+    u = u / m.p[0] * wm1;
+    u = clampf(u, 0.0f, wm1);
+    float v = clampf(pz, 0.0f, m.p[1]);
+    v = v / m.p[1] * hm1;
+    v = clampf(v, 0.0f, hm1);
+    const int u0 = (int)floorf(u), u1 = (int)ceilf(u), v0 = (int)floorf(v), v1 = (int)ceilf(v);
+    const float h00 = m.data[(size_t)u0 * m.dims1 + v0], h10 = m.data[(size_t)u1 * m.dims1 + v0];
+    const float h01 = m.data[(size_t)u0 * m.dims1 + v1], h11 = m.data[(size_t)u1 * m.dims1 + v1];
+    const float h0 = lerp_unity(h00, h01, v - (float)v0);
+    const float h1 = lerp_unity(h10, h11, v - (float)v0);
+    return lerp_unity(h0, h1, u - (float)u0);
+}
+
+constexpr int kYRun = 16;  // samples along y per thread
+
+// launch shape: 64 x 4 threads = 64 samples along x (the stride-1 axis) of 4 z-planes; a thread walks
+// kYRun samples along y; grid = (x segments, z quads, y runs)
 __global__ __launch_bounds__(256) void terrain_modify_kernel(float *__restrict__ grid, TerrainShape sh, TerrainModifierArgs m)
 {
-    const int ix = blockIdx.x * 64 + threadIdx.x, iy = blockIdx.y * 4 + threadIdx.y, iz = blockIdx.z;
-    if (ix >= m.dx || iy >= m.dy) return;
-    const int x = m.lx + ix, y = m.ly + iy, z = m.lz + iz;
+    const int ix = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y, iy0 = blockIdx.z * kYRun;
+    if (ix >= m.dx || iz >= m.dz) return;
+    const int x = m.lx + ix, z = m.lz + iz;
     // worldPos = new Vector3(x, y, z) * _voxelScale + TerrainOrigin (VoxelTerrain.cs:290)
     const float px = (float)x * sh.scale + sh.origin[0];
-    const float py = (float)y * sh.scale + sh.origin[1];
     const float pz = (float)z * sh.scale + sh.origin[2];
-    const uint64_t sample = (uint64_t)x + (uint64_t)sh.dim_x * ((uint64_t)y + (uint64_t)sh.dim_y * (uint64_t)z);
-    const float void0 = terrain_uniform(sh.seed, m.event, sample, 0u) - 2.0f;
-    const float full0 = terrain_uniform(sh.seed, m.event, sample, 1u) + 1.0f;
-    const float md = clampf(query_density(m, px, py, pz), void0, full0);
-    const float s = grid[sample];
-    float r;
-    if (m.add_or_erode) {
-        r = s > md ? s : md;  // Mathf.Max(S, md)
-    } else {
-        const float void1 = terrain_uniform(sh.seed, m.event, sample, 2u) - 2.0f;
-        const float full1 = terrain_uniform(sh.seed, m.event, sample, 3u) + 1.0f;
-        const float minus_md = -md;
-        r = clampf(s < minus_md ? s : minus_md, void1, full1);  // Clamp(Min(S, -md), void, full)
+    const float col = column_term(m, px, pz);
+    const int iy1 = iy0 + kYRun < m.dy ? iy0 + kYRun : m.dy;
+    for (int iy = iy0; iy < iy1; ++iy) {
+        const int y = m.ly + iy;
+        const float py = (float)y * sh.scale + sh.origin[1];
+        const uint64_t sample = (uint64_t)x + (uint64_t)sh.dim_x * ((uint64_t)y + (uint64_t)sh.dim_y * (uint64_t)z);
+        const float q = m.kind == 3 ? col - py : query_density(m, px, py, pz);  // IslandModifier: elevation - pos.y
+        const float md = clamp_drawn(q, sh.seed, m.event, sample, 0u);
+        const float s = grid[sample];
+        float r;
+        if (m.add_or_erode) {
+            r = s > md ? s : md;  // Mathf.Max(S, md)
+        } else {
+            const float minus_md = -md;
+            r = clamp_drawn(s < minus_md ? s : minus_md, sh.seed, m.event, sample, 2u);  // Clamp(Min(S, -md), void, full)
+        }
+        grid[sample] = r;
     }
-    grid[sample] = r;
 }
 
 hipError_t launch_terrain_fill(float *grid, long long n, uint64_t seed, int n_cus, hipStream_t stream)
@@ -122,8 +148,8 @@ hipError_t launch_terrain_fill(float *grid, long long n, uint64_t seed, int n_cu
 hipError_t launch_terrain_modify(float *grid, const TerrainShape &sh, const TerrainModifierArgs &m, hipStream_t stream)
 {
     if (m.dx <= 0 || m.dy <= 0 || m.dz <= 0) return hipSuccess;
-    if (m.dz > 65535 || (m.dy + 3) / 4 > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(terrain_modify_kernel, dim3((unsigned)((m.dx + 63) / 64), (unsigned)((m.dy + 3) / 4), (unsigned)m.dz),
+    if ((m.dz + 3) / 4 > 65535 || (m.dy + kYRun - 1) / kYRun > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(terrain_modify_kernel, dim3((unsigned)((m.dx + 63) / 64), (unsigned)((m.dz + 3) / 4), (unsigned)((m.dy + kYRun - 1) / kYRun)),
                        dim3(64, 4, 1), 0, stream, grid, sh, m);
     return hipGetLastError();
 }

@@ -63,7 +63,8 @@ struct vtmc_ctx {
     TerrainShape tshape{};
     bool has_terrain = false;
     uint32_t terrain_events = 0;
-    std::vector<int32_t> dirty;  // (bx,by,bz) of the last vtmc_terrain_update
+    std::vector<int32_t> dirty;  // (bx,by,bz) of the last vtmc_terrain_update, ordered by block id
+    bool dirty_is_all = false;   // ... or every block (the list is then materialised on demand only)
     uint64_t perm_seed = 0;
     bool perm_valid = false;
     std::string err;
@@ -701,6 +702,7 @@ int32_t vtmc_terrain_init(vtmc_ctx *ctx, int32_t width, int32_t elevation, int32
     ctx->tshape = sh;
     ctx->terrain_events = 0;
     ctx->dirty.clear();
+    ctx->dirty_is_all = false;
     ctx->has_terrain = true;
     return VTMC_OK;
 }
@@ -774,31 +776,35 @@ int32_t vtmc_terrain_update(vtmc_ctx *ctx, const vtmc_modifier *mods, int32_t n_
             b1[k] = (int)l;
             if (f > l) any = false;
         }
-        if (any)
+        if (any && n_marked < mark.size())
             for (int bz = b0[2]; bz <= b1[2]; ++bz)
-                for (int by = b0[1]; by <= b1[1]; ++by)
+                for (int by = b0[1]; by <= b1[1]; ++by) {
+                    uint8_t *row = &mark[(size_t)nbx * ((size_t)by + (size_t)nby * bz)];
                     for (int bx = b0[0]; bx <= b1[0]; ++bx) {
-                        uint8_t &mk = mark[(size_t)bx + (size_t)nbx * ((size_t)by + (size_t)nby * bz)];
-                        n_marked += !mk;
-                        mk = 1;
+                        n_marked += !row[bx];
+                        row[bx] = 1;
+                    }
+                }
+    }
+    // _nextUpdateblocks (VoxelTerrain.cs:321), ordered by block id; a full rebuild needs no list
+    ctx->dirty.clear();
+    ctx->dirty_is_all = n_marked == mark.size();
+    if (!ctx->dirty_is_all) {
+        ctx->dirty.reserve(n_marked * 3);
+        for (int bz = 0; bz < nbz; ++bz)
+            for (int by = 0; by < nby; ++by)
+                for (int bx = 0; bx < nbx; ++bx)
+                    if (mark[(size_t)bx + (size_t)nbx * ((size_t)by + (size_t)nby * bz)]) {
+                        ctx->dirty.push_back(bx);
+                        ctx->dirty.push_back(by);
+                        ctx->dirty.push_back(bz);
                     }
     }
-    // _nextUpdateblocks (VoxelTerrain.cs:321), ordered by block id
-    ctx->dirty.clear();
-    ctx->dirty.reserve(n_marked * 3);
-    for (int bz = 0; bz < nbz; ++bz)
-        for (int by = 0; by < nby; ++by)
-            for (int bx = 0; bx < nbx; ++bx)
-                if (mark[(size_t)bx + (size_t)nbx * ((size_t)by + (size_t)nby * bz)]) {
-                    ctx->dirty.push_back(bx);
-                    ctx->dirty.push_back(by);
-                    ctx->dirty.push_back(bz);
-                }
     if (n_dirty_blocks) *n_dirty_blocks = (int32_t)n_marked;
     // BatchUpdate (VoxelTerrain.cs:322-323: only when the set is not empty) on the resident grid
     BlockSpace sp = dense_space((const float *)ctx->terrain.p, W, E, H, 1, sh.dim_x, (int64_t)sh.dim_x * sh.dim_y, 1, 0);
     int n_volumes = 1;
-    if (n_marked != mark.size()) {  // a proper subset: device block list; every block: the dense streaming path
+    if (!ctx->dirty_is_all) {  // a proper subset: device block list; every block: the dense streaming path
         if (int rc = ensure(ctx, ctx->list, sizeof(int32_t) * 3 * std::max<size_t>(n_marked, 1))) return rc;
         if (n_marked > 0)
             VTMC_HIP(ctx, hipMemcpyAsync(ctx->list.p, ctx->dirty.data(), sizeof(int32_t) * 3 * n_marked, hipMemcpyHostToDevice, ctx->stream));
@@ -816,11 +822,24 @@ int32_t vtmc_terrain_dirty_blocks(vtmc_ctx *ctx, int32_t *dst, int32_t capacity_
 {
     if (!ctx) return VTMC_ERR_INVALID_ARG;
     if (!ctx->has_terrain) return fail(ctx, VTMC_ERR_NO_RESULT, "terrain_dirty_blocks before terrain_init");
-    const size_t n = ctx->dirty.size() / 3;
+    const TerrainShape &sh = ctx->tshape;
+    const int nbx = (sh.dim_x - 2) / 8, nby = (sh.dim_y - 2) / 8, nbz = (sh.dim_z - 2) / 8;
+    const size_t n = ctx->dirty_is_all ? (size_t)nbx * nby * nbz : ctx->dirty.size() / 3;
     if (n_blocks) *n_blocks = (int32_t)n;
     if (!dst) return VTMC_OK;  // size query
     if ((size_t)std::max(capacity_blocks, 0) < n) return fail(ctx, VTMC_ERR_CAPACITY, "capacity %d < %zu dirty blocks", capacity_blocks, n);
-    if (n) memcpy(dst, ctx->dirty.data(), n * 3 * sizeof(int32_t));
+    if (ctx->dirty_is_all) {
+        int32_t *o = dst;
+        for (int bz = 0; bz < nbz; ++bz)
+            for (int by = 0; by < nby; ++by)
+                for (int bx = 0; bx < nbx; ++bx) {
+                    *o++ = bx;
+                    *o++ = by;
+                    *o++ = bz;
+                }
+    } else if (n) {
+        memcpy(dst, ctx->dirty.data(), n * 3 * sizeof(int32_t));
+    }
     return VTMC_OK;
 }
 
