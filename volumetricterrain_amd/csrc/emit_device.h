@@ -280,7 +280,7 @@ __device__ __forceinline__ void stream_out_staged(const float *stage, float *__r
 template <bool FAST>
 __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_vert, size_t tri_base, int tri_budget,
                                                    size_t vert_base, int vert_budget, float *__restrict__ out_vertices,
-                                                   int *__restrict__ out_indices, int lane)
+                                                   int *__restrict__ out_indices, int lane, int ablate = 0)
 {
     const float *tile = L->tile;
     // pass 1: cases + compaction of the active cells (as the soup path)
@@ -306,7 +306,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
     int vdone = 0;   // vertices already written out
     auto flush_vertices = [&]() {
         VTMC_WAVE_SYNC();
-        int n_v = vrun - vdone;
+        int n_v = (ablate & 16) ? 0 : vrun - vdone;
         if (vdone + n_v > vert_budget) n_v = vert_budget - vdone > 0 ? vert_budget - vdone : 0;  // never outside the block's slice
         for (int s0 = 0; s0 < n_v; s0 += 64) {
             const int s = s0 + lane;
@@ -344,7 +344,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
         }
         vdone = vrun;
     };
-    for (int p0 = 0; p0 < 729; p0 += 64) {
+    for (int p0 = 0; p0 < ((ablate & 64) ? 0 : 729); p0 += 64) {
         if (vrun - vdone > kVlistCap - 192) flush_vertices();  // wave-uniform: the next step may add 192
         const int p = p0 + lane;
         unsigned flags = 0;
@@ -369,6 +369,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
     // pass 2 + index flush: triangle slots, 64 active cells per step
     auto flush = [&](int pending, size_t base) {
         VTMC_WAVE_SYNC();
+        if (ablate & 32) pending = 0;
         for (int s0 = 0; s0 < pending; s0 += 64) {
             const int s = s0 + lane;
             const size_t d0 = (base + (size_t)s0) * 3;

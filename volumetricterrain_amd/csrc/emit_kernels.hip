@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
 
         if constexpr (INDEXED)
             emit_block_indexed<FAST>(L, s_vert, tri_base, budget, (size_t)voffsets[b], (int)(voffsets[b + 1] - voffsets[b]), out,
-                                     out_indices, lane);
+                                     out_indices, lane, ablate);
         else
             emit_block_from_tile<FAST>(L, s_vert, tri_base, budget, b, out, lane, ablate);
         ai = ai_next;
@@ -161,9 +161,9 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
     dim3 g(wgs), blk(256);
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
     if (tune.emit_fast_math)
-        hipLaunchKernelGGL((emit_kernel<true, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, 0, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices);
+        hipLaunchKernelGGL((emit_kernel<true, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices);
     else
-        hipLaunchKernelGGL((emit_kernel<false, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, 0, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices);
+        hipLaunchKernelGGL((emit_kernel<false, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices);
     return hipGetLastError();
 }
 
