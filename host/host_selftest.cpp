@@ -152,6 +152,13 @@ static int gpu_resident_run(const std::string &out)
     vt.InsertModifier(std::make_shared<PlaneModifier>(6.3f, lo, up, true));
     vt.InsertModifier(std::make_shared<SphereModifier>(Vector3(10.0f, 8.0f, 15.0f), 5.5f, true));
     vt.InsertModifier(std::make_shared<CylinderModifier>(Vector3(2.0f, 5.0f, 6.0f), Vector3(1.0f, 0.3f, 0.5f), 20.0f, 2.2f, false));
+    {   // a small island on top (IslandModifier, the world-build modifier of TerrainEngine.cs:87)
+        const int res = 9;
+        std::vector<float> hm((size_t)res * res);
+        for (int u = 0; u < res; u++)
+            for (int v = 0; v < res; v++) hm[(size_t)u * res + v] = 4.0f + 0.5f * (float)((u * 3 + v * 5) % 7);
+        vt.InsertModifier(std::make_shared<IslandModifier>(hm, res, res, 20.0f, 24.0f, 9.0f, true));
+    }
     vt.Update();
     std::printf("resident: blocks %zu triangles %d\n", vt.LastUpdateBlocks().size(), vt.LastTriangleCount());
     vt.InsertModifier(std::make_shared<SphereModifier>(Vector3(5.0f, 4.0f, 9.0f), 2.0f, false));

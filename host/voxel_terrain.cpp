@@ -75,6 +75,32 @@ float CylinderModifier::QueryDensity(const Vector3 &pos) const
                      _radius - std::sqrt(start2pos.sqrMagnitude() - projLength * projLength)});
 }
 
+IslandModifier::IslandModifier(std::vector<float> heightmap, int widthRes, int heightRes, float islandWidth, float islandHeight,
+                               float maxElevation, bool addOrErode)
+    : _islandWidth(islandWidth), _islandHeight(islandHeight), _maxElevation(maxElevation), _widthRes(widthRes), _heightRes(heightRes),
+      _heightmap(std::move(heightmap))
+{
+    if (widthRes < 1 || heightRes < 1 || _heightmap.size() != (size_t)widthRes * heightRes) throw UnityException("heightmap size mismatch");
+    AddOrErode = addOrErode;
+}
+
+// IslandModifier.cs:45-73
+float IslandModifier::QueryDensity(const Vector3 &pos) const
+{
+    auto lerp = [](float a, float b, float t) { return a + (b - a) * Clamp(t, 0.0f, 1.0f); };  // Mathf.Lerp
+    float u = Clamp(pos.x, 0.0f, _islandWidth);
+    u = u / _islandWidth * (float)(_widthRes - 1);
+    u = Clamp(u, 0.0f, (float)(_widthRes - 1));
+    float v = Clamp(pos.z, 0.0f, _islandHeight);
+    v = v / _islandHeight * (float)(_heightRes - 1);
+    v = Clamp(v, 0.0f, (float)(_heightRes - 1));
+    const int u0 = (int)std::floor(u), u1 = (int)std::ceil(u), v0 = (int)std::floor(v), v1 = (int)std::ceil(v);
+    const float h00 = _heightmap[(size_t)u0 * _heightRes + v0], h10 = _heightmap[(size_t)u1 * _heightRes + v0];
+    const float h01 = _heightmap[(size_t)u0 * _heightRes + v1], h11 = _heightmap[(size_t)u1 * _heightRes + v1];
+    const float h0 = lerp(h00, h01, v - (float)v0), h1 = lerp(h10, h11, v - (float)v0);
+    return lerp(h0, h1, u - (float)u0) - pos.y;
+}
+
 // ---------------------------------------------------------------------------------------------
 // default backend: libvtmc.so
 // ---------------------------------------------------------------------------------------------
@@ -129,6 +155,9 @@ public:
             m.lower[0] = lo.x, m.lower[1] = lo.y, m.lower[2] = lo.z;
             m.upper[0] = up.x, m.upper[1] = up.y, m.upper[2] = up.z;
             std::memcpy(m.p, queue[i].desc.p, sizeof m.p);
+            m.data = queue[i].desc.data;
+            m.data_dims[0] = queue[i].desc.dims[0];
+            m.data_dims[1] = queue[i].desc.dims[1];
         }
         int32_t nDirty = 0, triNum = 0;
         if (vtmc_terrain_update(_ctx, mods.data(), (int32_t)mods.size(), &nDirty, &triNum) != VTMC_OK)
@@ -208,6 +237,7 @@ void VoxelTerrain::Update()
     if (_deviceResident) {
         // the whole of Update on the device: density writes, dirty set, BatchUpdate (VoxelTerrain.cs:262-325)
         std::vector<ExtractBackend::QueuedModifier> queue;
+        std::vector<std::shared_ptr<TerrainModifier>> alive;  // descriptors borrow from the modifiers (heightmap) until the call returns
         while (!_modifierQueue.empty()) {
             std::shared_ptr<TerrainModifier> modifier = _modifierQueue.front();
             _modifierQueue.pop_front();
@@ -217,6 +247,7 @@ void VoxelTerrain::Update()
             q.lower = modifier->LowerBound();
             q.upper = modifier->UpperBound();
             queue.push_back(q);
+            alive.push_back(std::move(modifier));
         }
         _lastUpdateBlocks.clear();
         _lastTriNum = 0;

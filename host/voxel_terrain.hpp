@@ -71,6 +71,8 @@ public:
 struct ModifierDesc {
     int kind = -1;
     float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float *data = nullptr;  // kind 3 (heightmap): float[dims[0]][dims[1]], owned by the modifier
+    int dims[2] = {0, 0};
 };
 
 // TerrainModifier.cs:19-33
@@ -143,6 +145,30 @@ public:
         d.p[5] = _axisDir.z;
         d.p[6] = _axisLength;
         d.p[7] = _radius;
+        return true;
+    }
+};
+
+// IslandModifier.cs:34-92: density = bilinear(_heightmap)(x, z) - y.  The reference fills _heightmap
+// from Island.GetElevation (island generation, out of scope): this mirror is handed the array.
+class IslandModifier : public TerrainModifier {
+public:
+    float _islandWidth, _islandHeight, _maxElevation;
+    int _widthRes, _heightRes;
+    std::vector<float> _heightmap;  // [u * _heightRes + v], as the C# float[widthRes, heightRes]
+    IslandModifier(std::vector<float> heightmap, int widthRes, int heightRes, float islandWidth, float islandHeight,
+                   float maxElevation, bool addOrErode = true);
+    Vector3 LowerBound() const override { return {0, std::numeric_limits<float>::lowest(), 0}; }
+    Vector3 UpperBound() const override { return {_islandWidth, _maxElevation, _islandHeight}; }
+    float QueryDensity(const Vector3 &pos) const override;
+    bool Describe(ModifierDesc &d) const override
+    {
+        d.kind = 3;
+        d.p[0] = _islandWidth;
+        d.p[1] = _islandHeight;
+        d.data = _heightmap.data();
+        d.dims[0] = _widthRes;
+        d.dims[1] = _heightRes;
         return true;
     }
 };

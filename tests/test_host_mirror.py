@@ -57,7 +57,10 @@ def test_host_mirror_device_resident(tmp_path, oracle_mod):
     ref = oracle_mod.Terrain(W, E, H, scale, origin, seed=4242)
     ref.update([oracle_mod.plane_modifier(6.3, (-100, -100), (100, 100)),
                 oracle_mod.sphere_modifier((10.0, 8.0, 15.0), 5.5),
-                oracle_mod.cylinder_modifier((2.0, 5.0, 6.0), (1.0, 0.3, 0.5), 20.0, 2.2, add=False)])
+                oracle_mod.cylinder_modifier((2.0, 5.0, 6.0), (1.0, 0.3, 0.5), 20.0, 2.2, add=False),
+                oracle_mod.heightmap_modifier(
+                    np.array([[4.0 + 0.5 * ((u * 3 + v * 5) % 7) for v in range(9)] for u in range(9)], np.float32),
+                    20.0, 24.0, 9.0)])
     dirty = ref.update([oracle_mod.sphere_modifier((5.0, 4.0, 9.0), 2.0, add=False)])
     grid = np.fromfile(tmp_path / "r_grid.f32", np.float32).reshape(W + 2, E + 2, H + 2)
     assert np.array_equal(grid, ref.grid)
