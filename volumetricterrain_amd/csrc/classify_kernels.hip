@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void classify_blocks_kernel(BlockSpace sp, Dev
 // are served by L2).  No per-cell output: cases are recomputed by the emit kernel from its LDS tile.
 // ----------------------------------------------------------------------------------------------
 template <bool WANT_V>
-__global__ __launch_bounds__(256) void classify_dense_kernel(BlockSpace sp, DeviceTables tb,
+__global__ __launch_bounds__(256, WANT_V ? 4 : 1) void classify_dense_kernel(BlockSpace sp, DeviceTables tb,
                                                               uint32_t *__restrict__ counts,
                                                               uint32_t *__restrict__ vcounts,
                                                               int nsegx, int n_bricks, int n_wgs, int ablate)
