@@ -52,3 +52,62 @@ def test_hip_path_matches_golden(exact):
                 assert np.array_equal(np.isnan(got[f]), nan)
                 dev = np.abs(np.where(nan, 0, got[f]) - np.where(nan, 0, want[f])).max()
                 assert dev <= (0.0 if exact else 1e-5), (name, f, dev)
+
+
+# -- terrain update + welded mesh (tests/golden/terrain_update.npz) ------------------------------------
+TERRAIN = dict(dims=(32, 16, 24), scale=0.5, origin=(-1.0, 0.5, 2.0), seed=20151)
+
+
+def _golden_modifiers(z, plane, sphere, cylinder, heightmap):
+    out = []
+    for row in z["modifiers"]:
+        k, add, a = int(row[0]), bool(row[1]), row[2:]
+        if k == 0:
+            out.append(plane(a[0], (a[1], a[2]), (a[3], a[4]), add))
+        elif k == 1:
+            out.append(sphere(a[0:3], a[3], add))
+        elif k == 2:
+            out.append(cylinder(a[0:3], a[3:6], a[6], a[7], add))
+        else:
+            out.append(heightmap(z["heightmap"], a[0], a[1], a[2], add))
+    return out
+
+
+def test_oracle_reproduces_golden_terrain(oracle_mod):
+    z = load("terrain_update.npz")
+    t = oracle_mod.Terrain(*TERRAIN["dims"], TERRAIN["scale"], TERRAIN["origin"], TERRAIN["seed"])
+    assert np.array_equal(t.grid, z["fill_zyx"].transpose(2, 1, 0))
+    dirty = t.update(_golden_modifiers(z, oracle_mod.plane_modifier, oracle_mod.sphere_modifier,
+                                       oracle_mod.cylinder_modifier, oracle_mod.heightmap_modifier))
+    assert np.array_equal(t.grid, z["grid_zyx"].transpose(2, 1, 0)) and np.array_equal(dirty, z["dirty"])
+    tris, offs, _ = oracle_mod.extract_grid(t.grid, dirty)
+    assert tris.tobytes() == z["triangles"].tobytes() and np.array_equal(offs, z["block_tri_offsets"])
+    verts, idx, voffs, _ = oracle_mod.extract_grid_indexed(t.grid, dirty)
+    assert verts.tobytes() == z["vertices"].tobytes() and np.array_equal(idx, z["indices"])
+    assert np.array_equal(voffs, z["block_vertex_offsets"])
+
+
+@pytest.mark.gpu
+def test_hip_terrain_matches_golden():
+    import volumetricterrain_amd as vt
+    z = load("terrain_update.npz")
+    mods = _golden_modifiers(z, vt.PlaneModifier, vt.SphereModifier, vt.CylinderModifier, vt.IslandModifier)
+    with vt.Extractor(0) as ex:
+        ex.set_tuning(emit_fast_math=0)
+        for indexed in (False, True):
+            ex.set_output_mode(indexed)
+            ex.terrain_init(*TERRAIN["dims"], TERRAIN["scale"], TERRAIN["origin"], TERRAIN["seed"])
+            assert np.array_equal(ex.terrain_read_samples(), z["fill_zyx"].transpose(2, 1, 0))
+            n_dirty, T = ex.terrain_update(mods)
+            assert np.array_equal(ex.terrain_read_samples(), z["grid_zyx"].transpose(2, 1, 0))
+            assert np.array_equal(ex.terrain_dirty_blocks(), z["dirty"]) and T == len(z["triangles"])
+            if indexed:
+                verts, idx, voffs, toffs = ex.read_indexed_mesh()
+                assert np.array_equal(idx, z["indices"]) and np.array_equal(voffs, z["block_vertex_offsets"])
+                assert np.array_equal(toffs, z["block_tri_offsets"])
+                assert verts.tobytes() == z["vertices"].tobytes()          # exact arithmetic mode: same bits
+            else:
+                got, offs = ex.read_triangles()
+                assert np.array_equal(offs, z["block_tri_offsets"]) and np.array_equal(got["block"], z["triangles"]["block"])
+                for f in ("p0", "p1", "p2", "n0", "n1", "n2"):
+                    assert np.array_equal(got[f], z["triangles"][f])
