@@ -35,20 +35,30 @@ __global__ __launch_bounds__(256) void classify_blocks_kernel(BlockSpace sp, Dev
         VTMC_WAVE_SYNC();  // previous iteration's reads are done before the tile is overwritten
         load_tile(tile, sp, block_origin(sp, b), lane);
         VTMC_WAVE_SYNC();
-        unsigned total = 0;
+        unsigned total = 0, zmask = 0;
+        bool any = false;
         unsigned lo = layer_nibble(tile, t0, 0);
 #pragma unroll
         for (int z = 0; z < 8; ++z) {
             unsigned hi = layer_nibble(tile, t0, z + 1);
             unsigned cs = lo | (hi << 4);
             lo = hi;
-            total += s_trinum[cs];
+            const unsigned n = s_trinum[cs];
+            total += n;
+            any |= n != 0u;
+            zmask |= (__builtin_amdgcn_ballot_w64(n != 0u) != 0 ? 1u : 0u) << z;
             if (cases) cases[512ll * b + 64 * z + lane] = (uint8_t)cs;
         }
         // wave sum of per-lane totals (<= 40 each)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off);
-        if (lane == 0) counts[b] = total;
+        {   // layers that hold a cell with triangles: bits 16-23 over y (lane >> 3), 24-31 over z, above the count
+            const u64 cols = __builtin_amdgcn_ballot_w64(any);
+            unsigned ymask = 0;
+#pragma unroll
+            for (int y = 0; y < 8; ++y) ymask |= ((cols >> (8 * y)) & 0xFFull) ? (1u << y) : 0u;
+            if (lane == 0) counts[b] = total | (ymask << 16) | (zmask << 24);
+        }
         if (vcounts) {
             // welded vertices = lattice edges of the 9^3 lattice with a sign change, enumerated as the
             // indexed emit does: point p = x + 9y + 81z, axes x, y, z
@@ -111,15 +121,19 @@ __global__ __launch_bounds__(256, WANT_V ? 4 : 1) void classify_dense_kernel(Blo
     xe = xe < sp.nx + 1 ? xe : sp.nx + 1;
     const float *brick_base = sp.base + v * sp.sv + (8ll * by) * sp.sy + (8ll * bz) * sp.sz;
 
-    unsigned vc = 0;
-    unsigned total = classify_brick_column<WANT_V>(sp, s_trinum, brick_base, gx, gxc, xe, lane, ablate, &vc);
+    unsigned vc = 0, rows = 0;
+    unsigned total = classify_brick_column<WANT_V>(sp, s_trinum, brick_base, gx, gxc, xe, lane, ablate, &vc, &rows);
     // 8-lane group sums = per-block counts
     total += __shfl_xor(total, 1);
     total += __shfl_xor(total, 2);
     total += __shfl_xor(total, 4);
     const int bx = segx * 8 + (lane >> 3);
     const int bid = v * sp.bpv + bx + sp.nbx * (by + sp.nby * bz);
-    if ((lane & 7) == 0 && bx < sp.nbx) counts[bid] = total;
+    rows |= (unsigned)__shfl_xor((int)rows, 1);
+    rows |= (unsigned)__shfl_xor((int)rows, 2);
+    rows |= (unsigned)__shfl_xor((int)rows, 4);
+    // a block holds at most 2560 triangles: the count shares its word with the block's row mask
+    if ((lane & 7) == 0 && bx < sp.nbx) counts[bid] = total | (rows << 16);
     if (WANT_V) {
         vc += __shfl_xor(vc, 1);
         vc += __shfl_xor(vc, 2);
@@ -130,6 +144,7 @@ __global__ __launch_bounds__(256, WANT_V ? 4 : 1) void classify_dense_kernel(Blo
 
 // ----------------------------------------------------------------------------------------------
 // scan: exclusive prefix sum of per-block triangle counts + compaction of the non-empty blocks.
+// A count word holds the triangle count in its low 16 bits (kCountMask) and the block's row mask above.
 // Replaces the single-address InterlockedAdd (CollectTriNum.compute:54), the 4-byte read-back
 // (VoxelTerrain.cs:394-395) and the append cursor (MarchingCube.compute:160-162).
 //   reduce : per 2048-block tile {triangles, non-empty blocks}
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const uint32_t *__rest
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         int i = base + k;
-        uint32_t c = i < n ? counts[i] : 0u;
+        uint32_t c = i < n ? counts[i] & kCountMask : 0u;
         sum += c;
         act += c != 0u;
     }
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restr
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         int i = base + k;
-        c[k] = i < n ? counts[i] : 0u;
+        c[k] = i < n ? counts[i] & kCountMask : 0u;
         sum += c[k];
         act += c[k] != 0u;
     }

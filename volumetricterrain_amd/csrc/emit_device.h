@@ -187,11 +187,15 @@ __device__ __forceinline__ void emit_flush2(EmitLds2 *L, int pending, size_t tri
 // (CollectTriNum.compute:48-51), compaction of the cells that hold triangles, triangle slots, then
 // one lane per triangle.  `budget` = the scan's triangle count of the block; flushes are clamped to
 // it so a classify/emit mismatch could never write outside the block's own slice of the buffer.
+// `rowmask` (bits 0-7: y layers, 8-15: z layers that hold a cell with triangles; 0xFFFF = unknown):
+// only tile rows next to such layers need to be valid, cells outside them are skipped.
 template <bool FAST>
 __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_vert, size_t tri_base, int budget,
-                                                     int block_id, float *__restrict__ out, int lane, int ablate)
+                                                     int block_id, float *__restrict__ out, int lane, int ablate,
+                                                     unsigned rowmask = 0xFFFFu)
 {
     const int t0 = (lane & 7) + 10 * (lane >> 3);
+    const bool y_live = (rowmask >> (lane >> 3)) & 1u;
     // pass 1
     int n_act = 0;
     unsigned lo = layer_nibble(L->tile, t0, 0);
@@ -202,7 +206,7 @@ __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_v
         lo = hi;
         const int cell = 64 * z + lane;
         L->cases[cell] = (unsigned char)cs;
-        const bool act = ((cs + 1u) & 0xFFu) > 1u;  // neither 0x00 nor 0xFF
+        const bool act = ((cs + 1u) & 0xFFu) > 1u && y_live && ((rowmask >> (8 + z)) & 1u);  // neither 0x00 nor 0xFF, in a live layer
         const u64 m = __builtin_amdgcn_ballot_w64(act);
         if (act) L->acell[n_act + (int)lanes_below(m)] = (unsigned short)cell;
         n_act += __builtin_popcountll(m);

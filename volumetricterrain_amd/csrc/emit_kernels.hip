@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
                                                     const uint32_t *__restrict__ totals, uint32_t capacity,
                                                     float *__restrict__ out, int group_log2, int ablate, unsigned *__restrict__ queue, int sub_log2,
                                                     const uint32_t *__restrict__ voffsets, const uint32_t *__restrict__ vtotals,
-                                                    uint32_t vcapacity, int *__restrict__ out_indices)
+                                                    uint32_t vcapacity, int *__restrict__ out_indices,
+                                                    const uint32_t *__restrict__ rowmasks)
 {
     using Lds = typename std::conditional<INDEXED, EmitLdsIdx, EmitLds2>::type;
     __shared__ Lds s_lds[kWavesPerWg];
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
     // their LDS destinations (lane index walks the stride-1 axis)
     unsigned toff[16];
     int tdst[16];
+    unsigned tyz[16];  // bit positions of the sample's y and z in the 10-bit row-need masks: y | z << 4
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         int idx = it * 64 + lane;
@@ -60,7 +62,20 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
         const int ix = sp.zfast ? c : a, iz = sp.zfast ? a : c;
         toff[it] = (unsigned)(ix * sp.sx + m * sp.sy + iz * sp.sz) * 4u;
         tdst[it] = ix + 10 * m + 100 * iz;
+        tyz[it] = (unsigned)m | ((unsigned)iz << 4);
     }
+    // Row masks from the classify pass (upper half of the block's count word): a tile row (y, z) is only fetched when a cell with triangles
+    // can touch it (its layer or one of the two below, on both axes) -- about 64 % of the rows on the
+    // benchmark field.  Rows not fetched keep stale values; pass 1 skips their cells.
+    auto load_rows = [&](const char *src, unsigned mask, float (&dst)[16]) {
+        const unsigned ym = mask & 0xFFu, zm = mask >> 8;
+        const unsigned ny = ym | (ym << 1) | (ym << 2), nz = zm | (zm << 1) | (zm << 2);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const bool need = ((ny >> (tyz[it] & 15u)) & (nz >> (tyz[it] >> 4)) & 1u) != 0u;
+            if (need && (!(ablate & 8) || it < 10)) dst[it] = *reinterpret_cast<const float *>(src + toff[it]);  // ablate 8: diagnostics
+        }
+    };
 
     // each XCD (blockIdx % 8 under round-robin dispatch; a speed heuristic only) sweeps one
     // contiguous eighth of the active list
@@ -94,20 +109,21 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
     };
     auto collect = [&]() { return ai_begin + (int)__builtin_amdgcn_readfirstlane(tick_raw); };
 
-    float pre[16];
+    float pre[16] = {};  // rows a block does not need keep whatever an earlier block left: never used
     int b_next = 0;
+    unsigned mask_next = 0xFFFFu;
     request();
     int ai = collect();
     request();
     int ai_next = collect();
     if (ai < ai_end) {
         b_next = active_list[ai];
-        const char *src = reinterpret_cast<const char *>(sp.base + block_origin(sp, b_next));
-#pragma unroll
-        for (int it = 0; it < 16; ++it) pre[it] = *reinterpret_cast<const float *>(src + toff[it]);
+        if (rowmasks) mask_next = rowmasks[b_next] >> 16;
+        load_rows(reinterpret_cast<const char *>(sp.base + block_origin(sp, b_next)), mask_next, pre);
     }
     for (int k = 0; ai < ai_end; ++k) {
         const int b = b_next;
+        const unsigned mask = mask_next;
         const size_t tri_base = offsets[b];
         const int budget = (int)(offsets[b + 1] - offsets[b]);  // the scan's count for this block
         VTMC_WAVE_SYNC();
@@ -115,10 +131,8 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
         for (int it = 0; it < 16; ++it) L->tile[tdst[it]] = pre[it];
         if (ai_next < ai_end) {  // prefetch the next block's tile; it lands while this one is processed
             b_next = active_list[(ablate & 2) ? ai_begin + (k & 3) : ai_next];
-            const char *src = reinterpret_cast<const char *>(sp.base + block_origin(sp, b_next));
-#pragma unroll
-            for (int it = 0; it < 16; ++it)
-                if (!(ablate & 8) || it < 10) pre[it] = *reinterpret_cast<const float *>(src + toff[it]);  // diagnostics: 62 % of the tile
+            if (rowmasks) mask_next = rowmasks[b_next] >> 16;
+            load_rows(reinterpret_cast<const char *>(sp.base + block_origin(sp, b_next)), mask_next, pre);
         }
         request();  // ticket for the block after next; collected at the bottom of this iteration
         VTMC_WAVE_SYNC();
@@ -127,14 +141,14 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
             emit_block_indexed<FAST>(L, s_vert, tri_base, budget, (size_t)voffsets[b], (int)(voffsets[b + 1] - voffsets[b]), out,
                                      out_indices, lane, ablate);
         else
-            emit_block_from_tile<FAST>(L, s_vert, tri_base, budget, b, out, lane, ablate);
+            emit_block_from_tile<FAST>(L, s_vert, tri_base, budget, b, out, lane, ablate, mask);
         ai = ai_next;
         ai_next = collect();
     }
 }
 
 hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets,
-                       const int32_t *active_list, const uint32_t *totals, uint32_t capacity,
+                       const int32_t *active_list, const uint32_t *totals, const uint32_t *counts_or_null, uint32_t capacity,
                        void *triangles, int n_cus, const Tuning &tune, unsigned *queue, hipStream_t stream)
 {
     int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : 3;  // LDS-limited residency: 3 x 48 KB
@@ -144,9 +158,9 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
     float *o = (float *)triangles;
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
     if (tune.emit_fast_math)
-        hipLaunchKernelGGL((emit_kernel<true, false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr);
+        hipLaunchKernelGGL((emit_kernel<true, false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr, tune.emit_row_masks ? counts_or_null : nullptr);
     else
-        hipLaunchKernelGGL((emit_kernel<false, false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr);
+        hipLaunchKernelGGL((emit_kernel<false, false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr, tune.emit_row_masks ? counts_or_null : nullptr);
     return hipGetLastError();
 }
 
@@ -161,9 +175,9 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
     dim3 g(wgs), blk(256);
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
     if (tune.emit_fast_math)
-        hipLaunchKernelGGL((emit_kernel<true, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices);
+        hipLaunchKernelGGL((emit_kernel<true, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, nullptr);
     else
-        hipLaunchKernelGGL((emit_kernel<false, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices);
+        hipLaunchKernelGGL((emit_kernel<false, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, nullptr);
     return hipGetLastError();
 }
 

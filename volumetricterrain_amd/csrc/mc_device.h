@@ -101,10 +101,13 @@ __device__ __forceinline__ unsigned extract9(u64 e0, u64 e1, int r0)
 // a sign change (every such edge carries exactly one mesh vertex): the x-, y- and z-edges starting
 // in this lane's 9 x 9 sample column, plus -- for the last lane of an 8-lane group -- the y- and
 // z-edges of the block's far x = 8 plane.  Same enumeration as the indexed emit (emit_device.h).
+// *rowmask (optional) receives, for this lane's cell column, the layers that hold a cell with triangles:
+// bits 0-7 over y, bits 8-15 over z.  OR-ed over a block they tell the emit kernel which rows of the
+// block's 10^3 tile it will touch at all.
 template <bool WANT_V = false>
 __device__ __forceinline__ unsigned classify_brick_column(const BlockSpace &sp, const unsigned char *s_trinum,
                                                           const float *brick_base, int gx, int gxc, int xe, int lane,
-                                                          int ablate = 0, unsigned *vcount = nullptr)
+                                                          int ablate = 0, unsigned *vcount = nullptr, unsigned *rowmask = nullptr)
 {
     // 81 row loads, lane-contiguous
     float val[9][9];
@@ -149,7 +152,7 @@ __device__ __forceinline__ unsigned classify_brick_column(const BlockSpace &sp, 
         and_all &= A[zz] & N[zz];
     }
 
-    unsigned total = 0;
+    unsigned total = 0, rows = 0, yacc = 0;
     const bool uniform = (or_all == 0u) || (and_all == 0x1FFu);
     if (WANT_V) {
         unsigned v = 0;
@@ -187,14 +190,30 @@ __device__ __forceinline__ unsigned classify_brick_column(const BlockSpace &sp, 
             const unsigned lo = NIB[zz], hi = NIB[zz + 1];
             const bool flat = ((lo | hi) == 0u) || ((lo & hi) == 0xFFFFFFFFu);
             if (__builtin_amdgcn_ballot_w64(!flat) == 0) continue;
+            if (!(ablate & 8)) {   // cells of this layer with a mixed case (= with triangles), one bit per nibble: not all 0, not all 1
+                const unsigned any = lo | hi, all = lo & hi;
+                const unsigned nz = (any | (any >> 1) | (any >> 2) | (any >> 3)) & 0x11111111u;
+                const unsigned full = (all & (all >> 1) & (all >> 2) & (all >> 3)) & 0x11111111u;
+                const unsigned act = nz & ~full;
+                yacc |= act;
+                rows |= act ? (0x100u << zz) : 0u;
+            }
 #pragma unroll
             for (int yy = 0; yy < 8; ++yy) {
                 unsigned cs = ((lo >> (4 * yy)) & 15u) | (((hi >> (4 * yy)) & 15u) << 4);
                 total += s_trinum[cs];
             }
         }
-        if (gx >= sp.nx) total = 0;  // lanes past the last cell of a partial segment
+        {   // nibble-spaced y bits -> bits 0-7
+            unsigned x = yacc;
+            x = (x | (x >> 3)) & 0x03030303u;
+            x = (x | (x >> 6)) & 0x000F000Fu;
+            x = (x | (x >> 12)) & 0xFFu;
+            rows |= x;
+        }
+        if (gx >= sp.nx) total = 0, rows = 0;  // lanes past the last cell of a partial segment
     }
+    if (rowmask) *rowmask = rows;
     return total;
 }
 

@@ -194,7 +194,8 @@ int run_staged(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t flag
                                               (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p, ctx->indices.p, ctx->n_cus, ctx->tune, queue, stream));
         else
             VTMC_HIP(ctx, launch_emit(sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const int32_t *)ctx->active.p,
-                                      (const uint32_t *)ctx->totals.p, (uint32_t)tcap, ctx->tris.p, ctx->n_cus, ctx->tune, queue, stream));
+                                      (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->counts.p, (uint32_t)tcap, ctx->tris.p,
+                                      ctx->n_cus, ctx->tune, queue, stream));
         VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
         VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->totals.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         if (indexed) VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 2, ctx->vtotals.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -667,6 +668,7 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     else if (k == "emit_dynamic") ctx->tune.emit_dynamic = value;
     else if (k == "emit_ablate") ctx->tune.emit_ablate = value;
     else if (k == "classify_ablate") ctx->tune.classify_ablate = value;
+    else if (k == "emit_row_masks") ctx->tune.emit_row_masks = value;
     else if (k == "emit_group_log2") ctx->tune.emit_group_log2 = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (k == "emit_wgs_per_cu") ctx->tune.emit_wgs_per_cu = value;
     else if (k == "sweep") ctx->tune.sweep = value;

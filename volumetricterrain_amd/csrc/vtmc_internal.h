@@ -58,6 +58,7 @@ struct Tuning {
     int emit_dynamic = 1;     // per-XCD ticket counters instead of a static round-robin over the active list
     int emit_ablate = 0;      // diagnostics only: 1 skip stores, 2 re-read hot tiles, 4 skip vertex math (output invalid)
     int classify_ablate = 0;  // diagnostics only: 1 no halo rows (output invalid)
+    int emit_row_masks = 1;   // emit loads only the tile rows next to cells with triangles (masks from classify)
     int emit_group_log2 = 0;  // each wave takes 2^g consecutive active-list entries per round
     int sweep = 0;            // 1: dense x-fastest volumes take the single-pass kernel (sweep_kernels.hip, slower so far: DESIGN.md); 0: classify -> scan -> emit
     int sweep_wgs_per_cu = 3;
@@ -74,6 +75,7 @@ constexpr int kCtrlWords = kCtrlTicket + 64 * kTicketGroups;
 
 // scan scratch layout
 constexpr int kQueueWords = 8 * 16 * 64;  // up to 16 ticket counters per XCD, 256 bytes apart
+constexpr uint32_t kCountMask = 0xFFFFu;  // counts[b]: triangles (<= 2560) | row mask << 16 (y layers 16-23, z layers 24-31)
 constexpr int kScanTile = 2048;  // block counts per scan workgroup (256 threads x 8)
 
 // Launch wrappers (mc_kernels.hip).  All asynchronous on `stream`; return hipGetLastError().
@@ -85,7 +87,7 @@ hipError_t launch_scan(const uint32_t *counts, int n_blocks, uint32_t *offsets, 
                        uint32_t *partials, uint32_t *totals, int bpv, int n_volumes,
                        uint32_t *volume_counts, hipStream_t stream);
 hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets,
-                       const int32_t *active_list, const uint32_t *totals, uint32_t capacity,
+                       const int32_t *active_list, const uint32_t *totals, const uint32_t *counts_or_null, uint32_t capacity,
                        void *triangles, int n_cus, const Tuning &tune, unsigned *queue, hipStream_t stream);
 
 hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets, const uint32_t *voffsets,
