@@ -13,12 +13,15 @@ constexpr int kWavesPerWg = 4;
 typedef unsigned long long u64;
 
 // LDS traffic of ONE wave is processed in issue order, so intra-wave producer/consumer hand-offs
-// through LDS only need the compiler kept from reordering -- no s_barrier.
+// through LDS need no s_barrier and no hardware wait -- only the compiler kept from moving LDS
+// accesses across the hand-off.  A wavefront-scope FENCE does that too, but hipcc lowers it to
+// s_waitcnt vmcnt(0) as well: every hand-off then also waits for the wave's outstanding global
+// stores (the triangle stream) to complete, which exposes the full store latency once per batch.
 #define VTMC_WAVE_SYNC()                                        \
     do {                                                        \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        asm volatile("" ::: "memory");                          \
         __builtin_amdgcn_wave_barrier();                        \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+        asm volatile("" ::: "memory");                          \
     } while (0)
 
 __device__ __forceinline__ unsigned lanes_below(u64 mask)
