@@ -36,3 +36,6 @@ def test_table_invariants(oracle_mod):
             if ((c >> a) & 1) != ((c >> b) & 1):
                 geo |= 1 << e
         assert used == edge[c] == geo
+    # every mixed case yields at least one triangle: the streaming classify derives a block's row mask
+    # from "case is neither 0 nor 255", the per-block classify from "triangle count != 0" -- the same set
+    assert tri_num[0] == 0 and tri_num[255] == 0 and (tri_num[1:255] > 0).all()
