@@ -85,7 +85,7 @@ int32_t vtmc_extract_grid(vtmc_ctx *ctx, const float *grid, int32_t nx, int32_t 
  * (c = cx + ncx*(cy + ncy*cz)) belongs to rank c % world_size.  Extracts this rank's chunks only,
  * chunk-major, blocks in canonical order inside each chunk.  chunk_counts receives for each LOCAL
  * chunk {vertex count, triangle count}; *n_local_chunks how many.  No collective is issued here:
- * the caller all-gathers chunk_counts (RCCL) -- see volumetricterrain_amd/sharding.py. */
+ * vtmc_allgather_volume_counts (below) is the RCCL all-gather that follows it. */
 int32_t vtmc_extract_grid_sharded(vtmc_ctx *ctx, const float *grid, int32_t nx, int32_t ny, int32_t nz,
                                   int64_t stride_x, int64_t stride_y, int64_t stride_z,
                                   int32_t chunk_cells, int32_t rank, int32_t world_size,
@@ -129,6 +129,16 @@ typedef struct vtmc_volume_batch {
 int32_t vtmc_extract_volumes_device(vtmc_ctx *ctx, const vtmc_volume_batch *batch, void *stream,
                                     uint32_t flags, int64_t *tri_count);
 
+/* The same extract in two halves, for hosts that keep the CPU out of the step (the multi-GPU driver):
+ * _async queues classify -> scan -> emit on `stream` and returns at once -- {T, nActive} stay in
+ * device memory, there is no mid-pipeline read-back (VoxelTerrain.cs:394-395) --; after it the per-
+ * volume counts are final on the stream, so vtmc_copy_volume_counts_device / vtmc_allgather_volume_counts
+ * may be queued behind it.  vtmc_extract_finish waits for the stream, returns T and -- when the
+ * triangle buffer turned out too small and the emit kernel refused to run -- grows it and runs the
+ * emit stage again.  Exactly one _finish per _async; no other extract_* in between. */
+int32_t vtmc_extract_volumes_device_async(vtmc_ctx *ctx, const vtmc_volume_batch *batch, void *stream, uint32_t flags);
+int32_t vtmc_extract_finish(vtmc_ctx *ctx, int64_t *tri_count);
+
 /* Device pointers to the results of the last extract_* (valid until the next extract_* / destroy):
  * triangles (T x 76 B), block_tri_offsets (n_blocks+1 x u32), volume_counts (n_volumes x
  * {vertices, triangles} u32 -- the array SURVEY.md 8e all-gathers).  Any out pointer may be NULL. */
@@ -144,15 +154,14 @@ int32_t vtmc_copy_volume_counts_device(vtmc_ctx *ctx, uint32_t *d_dst, int32_t c
 int32_t vtmc_reserve_triangles(vtmc_ctx *ctx, int64_t capacity);
 
 /* Per-stage device time of the last extract_* in milliseconds, measured with HIP events on the
- * stream the kernels ran on: ms[0] classify+count (the whole kernel in sweep mode), ms[1] scan,
+ * stream the kernels ran on: ms[0] classify+count, ms[1] scan,
  * ms[2] emit, ms[3] whole call.
  * The reference's only timing hook is the commented-out timer at VoxelTerrain.cs:363/467. */
 int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4]);
 
 /* Selects a kernel variant / launch shape, mainly for A/B measurements in one process.  Keys that
  * keep results within the parity bar: "emit_fast_math" (1: v_rcp / v_rsq / fma, default; 0: correctly
- * rounded, bit-compatible with the CPU oracle), "sweep" (1: the single-pass kernel for dense
- * x-fastest volumes, default 0), "emit_wgs_per_cu", "sweep_wgs_per_cu", "emit_dynamic",
+ * rounded, bit-compatible with the CPU oracle), "emit_wgs_per_cu", "emit_dynamic",
  * "emit_sub_log2", "emit_group_log2".  "emit_ablate" / "classify_ablate" switch parts of a kernel
  * off for diagnosis and make the output INVALID.  Defaults are the shipped configuration. */
 int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value);
@@ -276,6 +285,68 @@ int32_t vtmc_density_fill_device_async(vtmc_ctx *ctx, const vtmc_density_params 
                                        int32_t dim_x, int32_t dim_y, int32_t dim_z,
                                        int64_t stride_x, int64_t stride_y, int64_t stride_z,
                                        int64_t volume_stride, float *d_out, void *stream);
+
+/* Device time in milliseconds of the density kernel the last vtmc_density_fill_device[_async] queued
+ * (HIP events on the stream it ran on; waits for that kernel only). */
+int32_t vtmc_last_fill_ms(vtmc_ctx *ctx, float *ms);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU: one context per GPU / process, chunk c -> rank c % world_size, and ONE collective --
+ * an RCCL all-gather (over xGMI) of the per-chunk {vertices, triangles} pairs -- after which every
+ * rank derives the global offsets with a local exclusive scan.  New in the build: the
+ * reference is single-process / single-GPU; the call sits where BatchUpdate hands its results to the
+ * host (VoxelTerrain.cs:426-446).  librccl is bound at run time on the first vtmc_comm_* call.
+ * ------------------------------------------------------------------------------------------ */
+#define VTMC_COMM_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+
+/* Rank 0 draws the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by the host's own
+ * means (the C# host: its launcher's socket / file; bench.py: torch.distributed broadcast). */
+int32_t vtmc_comm_unique_id(uint8_t id[VTMC_COMM_ID_BYTES]);
+
+/* Collective over all ranks: creates this context's communicator on its device (ncclCommInitRank). */
+int32_t vtmc_comm_init_rank(vtmc_ctx *ctx, const uint8_t id[VTMC_COMM_ID_BYTES], int32_t rank, int32_t world_size);
+int32_t vtmc_comm_destroy(vtmc_ctx *ctx);
+
+/* All-gather of volume_counts of the last extract_* on `stream` (NULL = the context's stream),
+ * asynchronously: d_all_counts (device, world_size x volumes_per_rank x {vertices, triangles} u32)
+ * receives rank r's pairs at [r * volumes_per_rank ...), zero-padded where a rank owns fewer volumes.
+ * No host synchronisation: the caller orders later work on the same stream. */
+int32_t vtmc_allgather_volume_counts(vtmc_ctx *ctx, uint32_t *d_all_counts, int32_t volumes_per_rank, void *stream);
+
+/* Blocking device -> host copy on `stream` (NULL = the context's stream) through the library's own
+ * HIP runtime: for hosts that hold device pointers from vtmc_device_results and no HIP binding. */
+int32_t vtmc_copy_to_host(vtmc_ctx *ctx, const void *d_src, void *dst, int64_t bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Persisted chunks (layout: volumetricterrain_amd/chunkfile.py -- 64-byte
+ * header, then 16-byte aligned sections).  New in the build: the reference keeps its grid in memory
+ * only (VoxelTerrain.cs:145-149).  The file image is assembled on the device.
+ * ------------------------------------------------------------------------------------------ */
+#define VTMC_CHUNK_SAMPLES 1u /* f32[(cells+2)^3], x fastest */
+#define VTMC_CHUNK_SOUP 2u    /* 76-byte records, `block` relative to the chunk */
+#define VTMC_CHUNK_INDEXED 4u /* vert_offsets, vertices, indices */
+
+/* Writes volume `volume` of the last vtmc_extract_volumes_device / vtmc_extract_grid (its samples when
+ * with_samples != 0 -- the input of that extract must still be resident --, its block offsets rebased to
+ * 0 and its mesh in the output mode that extract ran in).  origin = global sample index of the chunk. */
+int32_t vtmc_chunk_write(vtmc_ctx *ctx, const char *path, int32_t volume, const int32_t origin[3], int32_t with_samples);
+
+typedef struct vtmc_chunk_view {
+    int32_t origin[3];
+    int32_t cells[3];
+    uint32_t flags, n_blocks, n_triangles, n_vertices;
+    const float *d_samples;            /* NULL when the section is absent; strides (1, cells[0]+2, (cells[0]+2)*(cells[1]+2)) */
+    const uint32_t *d_tri_offsets;     /* n_blocks + 1 */
+    const vtmc_triangle *d_triangles;
+    const uint32_t *d_vert_offsets;
+    const vtmc_vertex *d_vertices;
+    const int32_t *d_indices;
+} vtmc_chunk_view;
+
+/* Uploads a chunk file as one image and returns DEVICE pointers to its sections (owned by the
+ * context, valid until the next vtmc_chunk_read / vtmc_chunk_write / vtmc_destroy): d_samples can be
+ * handed straight back to vtmc_extract_volumes_device. */
+int32_t vtmc_chunk_read(vtmc_ctx *ctx, const char *path, vtmc_chunk_view *out);
 
 /* Library / build identification: "vtmc <version> gfx950". */
 const char *vtmc_version(void);

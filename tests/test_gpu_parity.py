@@ -11,7 +11,6 @@ import fields
 pytestmark = pytest.mark.gpu
 
 ATOL = 1e-5  # north_star tolerance for positions / normals
-SWEEP_DEFAULT = 0  # shipped pipeline: classify -> scan -> emit (sweep=1: the single-pass kernel)
 
 
 @pytest.fixture(scope="module")
@@ -41,19 +40,18 @@ def assert_tris_match(got, want, atol=ATOL):
 
 def test_exact_mode_is_bit_compatible_with_oracle(ex, oracle_mod):
     """emit_fast_math=0: correctly rounded divide / sqrt, contraction off => identical floats
-    (up to the sign of zero), in both pipelines.  The shipped default (v_rcp / v_rsq / fma) stays
-    within ATOL and is what every other test runs."""
+    (up to the sign of zero).  The shipped default (v_rcp / v_rsq / fma) stays within ATOL and is
+    what every other test runs."""
     g = oracle_mod.density_volume("perlin3d", 64)
     want, want_offs, _ = oracle_mod.extract_grid(g, threads=8)
     try:
-        for sweep in (0, 1):
-            ex.set_tuning(emit_fast_math=0, sweep=sweep)
-            assert ex.extract_grid(g) == len(want)
-            got, offs = ex.read_triangles()
-            assert np.array_equal(offs, want_offs)
-            assert assert_tris_match(got, want, atol=0.0) == 0.0
+        ex.set_tuning(emit_fast_math=0)
+        assert ex.extract_grid(g) == len(want)
+        got, offs = ex.read_triangles()
+        assert np.array_equal(offs, want_offs)
+        assert assert_tris_match(got, want, atol=0.0) == 0.0
     finally:
-        ex.set_tuning(emit_fast_math=1, sweep=SWEEP_DEFAULT)
+        ex.set_tuning(emit_fast_math=1)
     assert ex.extract_grid(g) == len(want)
     worst = assert_tris_match(ex.read_triangles(False), want)
     assert worst <= 2e-6, worst     # fast path: observed ~5e-7, bar 1e-5
@@ -109,38 +107,73 @@ def test_grid_in_place_matches_oracle(ex, oracle_mod, order):
     assert_tris_match(got, want)
 
 
-@pytest.mark.parametrize("sweep", [1, 0])
-def test_non_cubic_and_partial_segments(ex, oracle_mod, sweep):
-    """nx = 40 / 72 exercise partial 64-lane segments of the streaming classify; sweep=1 is the
-    single-pass kernel (default), sweep=0 the classify -> scan -> emit kernels."""
-    try:
-        ex.set_tuning(sweep=sweep)
-        for n in ((40, 16, 24), (72, 8, 16), (136, 8, 8), (32, 8, 8), (200, 24, 8)):
-            g = fields.random_field(n, seed=n[0])
-            want, want_offs, _ = oracle_mod.extract_grid(g, threads=8)
-            assert ex.extract_grid(g) == len(want)
-            got, offs = ex.read_triangles()
-            assert np.array_equal(offs, want_offs)
-            assert_tris_match(got, want)
-    finally:
-        ex.set_tuning(sweep=SWEEP_DEFAULT)
+def test_non_cubic_and_partial_segments(ex, oracle_mod):
+    """nx = 40 / 72 ... exercise partial 64-lane segments of the streaming classify."""
+    for n in ((40, 16, 24), (72, 8, 16), (136, 8, 8), (32, 8, 8), (200, 24, 8)):
+        g = fields.random_field(n, seed=n[0])
+        want, want_offs, _ = oracle_mod.extract_grid(g, threads=8)
+        assert ex.extract_grid(g) == len(want)
+        got, offs = ex.read_triangles()
+        assert np.array_equal(offs, want_offs)
+        assert_tris_match(got, want)
 
 
-def test_sweep_and_staged_pipelines_agree_bitwise(ex, oracle_mod):
-    """The single-pass kernel and the three-stage pipeline share the emit routine: same bytes out.
-    A buffer that is too small on the first call (reserve 1) exercises the count-then-regrow path."""
-    g = oracle_mod.density_volume("perlin3d", 128)
-    outs = []
-    try:
-        for sweep in (1, 0):
-            ex.set_tuning(sweep=sweep)
-            ex.reserve_triangles(1)
-            T = ex.extract_grid(g)
-            tris, offs = ex.read_triangles()
-            outs.append((T, tris.tobytes(), offs.tobytes()))
-    finally:
-        ex.set_tuning(sweep=SWEEP_DEFAULT)
-    assert outs[0] == outs[1]
+def test_queued_extract_regrows_and_equals_blocking(ex, oracle_mod):
+    """vtmc_extract_volumes_device_async + vtmc_extract_finish give the bytes the blocking call gives.
+    A buffer that is too small on the first launch (reserve 1) exercises the path where the emit
+    kernel refuses to run, finish() grows the buffer and queues the emit stage again; the per-volume
+    counts are already final behind the queued call (what the all-gather is queued on)."""
+    import torch
+    c, dim = 64, 66
+    chunks = [oracle_mod.density_volume("perlin3d", c, origin=(64 * i, 0, 64)) for i in range(3)]
+    d = torch.from_numpy(np.stack([np.ascontiguousarray(g.transpose(2, 1, 0)) for g in chunks])).cuda()
+    T0 = ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 3, dim ** 3)
+    want, want_offs = ex.read_triangles()
+    counts = torch.zeros((3, 2), dtype=torch.int32, device="cuda")
+    ex.reserve_triangles(1)
+    ex.extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 3, dim ** 3)
+    ex.copy_volume_counts_device(counts.data_ptr(), 3)       # queued behind the scan, before finish
+    assert ex.extract_finish() == T0
+    got, offs = ex.read_triangles()
+    assert got.tobytes() == want.tobytes() and np.array_equal(offs, want_offs)
+    torch.cuda.synchronize()
+    vc = counts.cpu().numpy()
+    assert vc[:, 1].sum() == T0 and np.array_equal(vc[:, 0], 3 * vc[:, 1])
+    with pytest.raises(Exception) as e:      # one finish per queued extract
+        ex.extract_finish()
+    assert e.value.code == -5
+
+
+def test_capacity_and_range_errors(ex, oracle_mod):
+    """VTMC_ERR_CAPACITY: a destination smaller than T (SURVEY 8b "validate capacity >= T");
+    VTMC_ERR_TOO_LARGE: more than 2^31-1 triangles -- the scan's total is kept in 64 bits, so a noise
+    field whose count passes 2^32 is refused instead of wrapping to a small count."""
+    import ctypes
+    import torch
+    import volumetricterrain_amd as vt
+    g = oracle_mod.density_volume("perlin3d", 32)
+    T = ex.extract_grid(g)
+    assert T > 100
+    buf = np.zeros(T - 1, vt.TRI_DTYPE)
+    rc = ex._L.vtmc_read_triangles(ex._h, buf.ctypes.data_as(ctypes.c_void_p), T - 1, None)
+    assert rc == -3 and b"capacity" in ex._L.vtmc_last_error(ex._h)
+    assert not buf.view(np.uint8).any()                        # nothing was written
+    rc = ex._L.vtmc_read_triangles(ex._h, None, T, None)
+    assert rc == -1
+    # white noise holds 820 / 256 = 3.2 triangles per cell: 1024 x 1024 x 1408 cells -> ~4.7e9 > 2^32
+    n = (1024, 1024, 1408)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    d = torch.rand((n[2] + 2) * (n[1] + 2) * (n[0] + 2), generator=gen, device="cuda") - 0.5
+    ex.reserve_triangles(1024)
+    with pytest.raises(vt.VtmcError) as e:
+        ex.extract_volumes_device(d.data_ptr(), n, (1, n[0] + 2, (n[0] + 2) * (n[1] + 2)), 1, 0)
+    assert e.value.code == -6 and "exceed the int32 range" in str(e.value)
+    import re
+    reported = int(re.search(r"(\d+) triangles", str(e.value)).group(1))
+    assert reported > 2 ** 32
+    del d
+    # the context stays usable
+    assert ex.extract_grid(g) == T
 
 
 def test_dirty_block_list(ex, oracle_mod):
@@ -215,9 +248,21 @@ def test_device_volume_batch_matches_grid(ex, oracle_mod):
     # volume_counts = {vertices, triangles} per chunk, the array that gets all-gathered
     _, _, vc_ptr = ex.device_results()
     from volumetricterrain_amd import sharding
-    vc = sharding.copy_device_u32(vc_ptr, 16).reshape(8, 2)
+    vc = ex.copy_u32(vc_ptr, 16).reshape(8, 2)
     assert np.array_equal(vc[:, 1], [len(w) for w in want])
     assert np.array_equal(vc[:, 0], 3 * vc[:, 1])
+
+
+class _DeviceArray:
+    """Exposes a raw device pointer to torch through __cuda_array_interface__ (no copy, no HIP binding)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+
+def device_view_i32(ptr, count):
+    import torch
+    return torch.as_tensor(_DeviceArray(ptr, count), device="cuda")
 
 
 def test_sharded_host_entry(ex, oracle_mod):
@@ -274,17 +319,32 @@ def test_config_1024_chunked_properties(ex, oracle_mod):
     T = ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), len(origins), dim ** 3)
     tri_ptr, off_ptr, vc_ptr = ex.device_results()
     bpv = (c // 8) ** 3
-    offs = sharding.copy_device_u32(off_ptr, len(origins) * bpv + 1)
-    vc = sharding.copy_device_u32(vc_ptr, 2 * len(origins)).reshape(-1, 2)
+    offs = ex.copy_u32(off_ptr, len(origins) * bpv + 1)
+    vc = ex.copy_u32(vc_ptr, 2 * len(origins)).reshape(-1, 2)
     assert offs[0] == 0 and offs[-1] == T and (np.diff(offs.astype(np.int64)) >= 0).all()
     assert vc[:, 1].sum() == T
     assert np.array_equal(np.diff(offs.astype(np.int64))[: bpv * len(origins)].reshape(len(origins), bpv).sum(1), vc[:, 1])
-    # sampled chunks against the oracle, fed the SAME device-generated array
+    # EVERY block of EVERY chunk against the oracle's count pass (CollectTriNum.compute:41-64 restated),
+    # fed the SAME device-generated array: all 2 097 152 block offsets
+    blocks = oracle_mod.all_blocks(c, c, c)
+    threads = oracle_mod.max_threads()
+    o_offs = np.empty(bpv + 1, np.int32)
+    offs64 = offs.astype(np.int64)
+    step = 32
+    for v0 in range(0, len(origins), step):
+        host = d[v0 * dim ** 3:(v0 + step) * dim ** 3].cpu().numpy()
+        for v in range(v0, min(v0 + step, len(origins))):
+            sub = host[(v - v0) * dim ** 3:(v - v0 + 1) * dim ** 3]
+            n_v = oracle_mod.lib().vto_extract_grid(oracle_mod._p(sub), 1, dim, dim * dim, oracle_mod._p(blocks), bpv, None, 0,
+                                                    oracle_mod._p(o_offs), None, threads)
+            assert n_v == vc[v, 1], "chunk %d: %d triangles, oracle %d" % (v, vc[v, 1], n_v)
+            assert np.array_equal(offs64[v * bpv:(v + 1) * bpv + 1] - offs64[v * bpv], o_offs), "chunk %d block offsets" % v
+    # sampled chunks in full (positions / normals / block ids)
     for v in (0, 77, 300, 511):
         sub = d[v * dim ** 3:(v + 1) * dim ** 3].cpu().numpy().reshape(dim, dim, dim).transpose(2, 1, 0)
         want, want_offs, _ = oracle_mod.extract_grid(sub, threads=oracle_mod.max_threads())
         assert vc[v, 1] == len(want)
-        got = sharding.copy_device_bytes(tri_ptr + 76 * int(offs[v * bpv]), 76 * len(want)).view(vt.TRI_DTYPE)
+        got = ex.copy_to_host(tri_ptr + 76 * int(offs[v * bpv]), 76 * len(want)).view(vt.TRI_DTYPE)
         want = want.copy()
         want["block"] += v * bpv
         assert_tris_match(got, want)
@@ -308,13 +368,13 @@ def test_config_streaming_fbm8_double_buffered(ex, oracle_mod):
         total, counts = 0, []
         for k, org, T, bex in st.batches():
             tri_ptr, off_ptr, vc_ptr = bex.device_results()
-            vc = sharding.copy_device_u32(vc_ptr, 2 * len(org)).reshape(-1, 2)
+            vc = bex.copy_u32(vc_ptr, 2 * len(org)).reshape(-1, 2)
             counts.append(vc)
             total += T
             if k == 2:   # keep the last chunk of the last batch for the oracle
-                offs = sharding.copy_device_u32(off_ptr, len(org) * st.bpv + 1)
+                offs = bex.copy_u32(off_ptr, len(org) * st.bpv + 1)
                 lo, hi = int(offs[(len(org) - 1) * st.bpv]), int(offs[len(org) * st.bpv])
-                kept = (org[-1].copy(), sharding.copy_device_bytes(tri_ptr + 76 * lo, 76 * (hi - lo)).view(vt.TRI_DTYPE).copy())
+                kept = (org[-1].copy(), bex.copy_to_host(tri_ptr + 76 * lo, 76 * (hi - lo)).view(vt.TRI_DTYPE).copy())
         counts = np.concatenate(counts)
         all_origins = st.origins.copy()
         prm = st.params
@@ -324,7 +384,7 @@ def test_config_streaming_fbm8_double_buffered(ex, oracle_mod):
     ex.density_fill_device(prm, all_origins, (dim, dim, dim), (1, dim, dim * dim), dim ** 3, d.data_ptr())
     T1 = ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), len(all_origins), dim ** 3)
     _, _, vc_ptr = ex.device_results()
-    vc1 = sharding.copy_device_u32(vc_ptr, 2 * len(all_origins)).reshape(-1, 2)
+    vc1 = ex.copy_u32(vc_ptr, 2 * len(all_origins)).reshape(-1, 2)
     assert T1 == total and np.array_equal(vc1, counts)
     # the kept chunk against the oracle, fed the device-generated samples
     v = len(all_origins) - 1
@@ -352,13 +412,12 @@ def test_max_size_single_grid_equals_chunked(ex, oracle_mod):
     T = ex.extract_volumes_device(whole.data_ptr(), (n, n, n), (1, dim, dim * dim), 1, 0)
     tri_ptr, off_ptr, _ = ex.device_results()
     nb = n // 8
-    counts = np.diff(sharding.copy_device_u32(off_ptr, nb ** 3 + 1).astype(np.int64)).reshape(nb, nb, nb)   # [bz, by, bx]
+    counts = np.diff(ex.copy_u32(off_ptr, nb ** 3 + 1).astype(np.int64)).reshape(nb, nb, nb)   # [bz, by, bx]
     k = c // 8
     per_chunk_whole = counts.reshape(nb // k, k, nb // k, k, nb // k, k).sum(axis=(1, 3, 5)).reshape(-1)     # chunk = cx + ncx*(cy + ncy*cz)
 
     def float_checksum(ptr, count):
-        t = torch.empty(count * 19, dtype=torch.int32, device="cuda")
-        sharding._hiprt().hipMemcpy(t.data_ptr(), ptr, 76 * count, 3)   # device -> device
+        t = device_view_i32(ptr, count * 19)   # zero-copy view of the library's triangle buffer
         words = t.view(-1, 19)[:, :18].to(torch.int64) & 0xFFFFFFFF
         w = words % 1000003
         return int(words.sum().item()), int((w * w % 1000003).sum().item())
@@ -371,7 +430,7 @@ def test_max_size_single_grid_equals_chunked(ex, oracle_mod):
     ex.density_fill_device(prm, origins, (cdim, cdim, cdim), (1, cdim, cdim * cdim), cdim ** 3, d.data_ptr())
     T2 = ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, cdim, cdim * cdim), len(origins), cdim ** 3)
     tri_ptr, _, vc_ptr = ex.device_results()
-    vc = sharding.copy_device_u32(vc_ptr, 2 * len(origins)).reshape(-1, 2)
+    vc = ex.copy_u32(vc_ptr, 2 * len(origins)).reshape(-1, 2)
     assert T2 == T == 42485756
     assert np.array_equal(vc[:, 1].astype(np.int64), per_chunk_whole)
     assert float_checksum(tri_ptr, T2) == sum_whole
@@ -431,3 +490,86 @@ def test_streaming_shards_cover_the_world(ex, oracle_mod):
     merged = sharding.interleave_rank_counts([p[1] for p in parts], 2)
     assert total > 0 and parts[0][0] + parts[1][0] == total
     assert np.array_equal(merged, counts)
+
+
+def test_rccl_allgather_of_counts_through_the_c_abi(ex, oracle_mod):
+    """The path's one collective behind the C ABI (vtmc_comm_* + vtmc_allgather_volume_counts): a
+    world of one rank round-trips its per-chunk {vertices, triangles} through RCCL, padded to
+    volumes_per_rank.  (Two ranks on one device are refused by RCCL; the multi-rank path is the same
+    call with world_size > 1 and is covered on CPU by tests/test_sharding_gloo.py's layout checks.)"""
+    import torch
+    import volumetricterrain_amd as vt
+    c, dim = 32, 34
+    chunks = [oracle_mod.density_volume("perlin3d", c, origin=(32 * i, 0, 0)) for i in range(3)]
+    d = torch.from_numpy(np.stack([np.ascontiguousarray(g.transpose(2, 1, 0)) for g in chunks])).cuda()
+    want = [oracle_mod.extract_grid(g, count_only=True)[0] for g in chunks]
+    with vt.Extractor(0) as e2:
+        with pytest.raises(vt.VtmcError) as err:
+            e2.allgather_volume_counts(0, 4)
+        assert err.value.code == -5                       # no communicator yet
+        e2.comm_init_rank(e2.comm_unique_id(), 0, 1)
+        gathered = torch.full((1, 5, 2), 0x7FFFFFFF, dtype=torch.int32, device="cuda")
+        e2.extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 3, dim ** 3)
+        e2.allgather_volume_counts(gathered.data_ptr(), 5)     # queued behind the scan of the pending extract
+        T = e2.extract_finish()
+        torch.cuda.synchronize()
+        g = gathered.cpu().numpy()[0]
+        assert T == sum(want) and list(g[:3, 1]) == want and np.array_equal(g[:3, 0], 3 * g[:3, 1])
+        assert not g[3:].any()                             # zero padding up to volumes_per_rank
+        with pytest.raises(vt.VtmcError) as err:
+            e2.allgather_volume_counts(gathered.data_ptr(), 2)
+        assert err.value.code == -3
+        e2.comm_destroy()
+
+
+@pytest.mark.parametrize("indexed", [False, True])
+def test_chunk_file_written_and_reloaded_on_the_device(ex, oracle_mod, tmp_path, indexed):
+    """SURVEY 8f rank 4 on the device: extract a batch, persist one chunk (image packed by device
+    kernels), reload it in another context, re-extract from the reloaded samples: bit-identical mesh.
+    The file is also read by the host-side reader (chunkfile.py) and compared with the oracle."""
+    import torch
+    import volumetricterrain_amd as vt
+    from volumetricterrain_amd import chunkfile
+    c, dim, bpv = 32, 34, 64
+    orgs = [(0, 0, 0), (32, 0, 0), (0, 32, 64)]
+    chunks = [oracle_mod.density_volume("perlin3d", 128, origin=o, dims=(dim, dim, dim)) for o in orgs]
+    d = torch.from_numpy(np.stack([np.ascontiguousarray(g.transpose(2, 1, 0)) for g in chunks])).cuda()
+    path = tmp_path / "chunk2.vtchunk"
+    try:
+        ex.set_output_mode(indexed)
+        ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 3, dim ** 3)
+        ex.chunk_write(path, 2, orgs[2], with_samples=True)
+        f = chunkfile.read_chunk(path)
+        assert f["origin"] == orgs[2] and f["cells"] == (c, c, c) and f["flags"] == (1 | (4 if indexed else 2))
+        assert np.array_equal(f["samples"], np.ascontiguousarray(chunks[2].transpose(2, 1, 0)).ravel())
+        if indexed:
+            verts, idx, voffs, toffs = oracle_mod.extract_grid_indexed(chunks[2])
+            assert np.array_equal(f["tri_offsets"], toffs.astype(np.uint32)) and np.array_equal(f["vert_offsets"], voffs.astype(np.uint32))
+            assert np.array_equal(f["indices"], idx)
+            assert np.abs(f["vertices"]["position"] - verts["position"]).max() <= ATOL
+            assert np.abs(f["vertices"]["normal"] - verts["normal"]).max() <= ATOL
+        else:
+            want, want_offs, _ = oracle_mod.extract_grid(chunks[2])
+            assert np.array_equal(f["tri_offsets"], want_offs.astype(np.uint32))
+            assert_tris_match(f["triangles"], want)            # `block` is chunk-relative in the file
+        with vt.Extractor(0) as e2:
+            e2.set_output_mode(indexed)
+            view = e2.chunk_read(path)
+            assert (view.n_blocks, view.n_triangles) == (bpv, len(f["indices"]) if indexed else len(f["triangles"]))
+            T = e2.extract_volumes_device(view.d_samples, (c, c, c), (1, dim, dim * dim), 1, 0)
+            assert T == view.n_triangles
+            if indexed:
+                v2, i2, vo2, to2 = e2.read_indexed_mesh()
+                assert v2.tobytes() == f["vertices"].tobytes() and np.array_equal(i2, f["indices"])
+                assert np.array_equal(vo2, f["vert_offsets"]) and np.array_equal(to2, f["tri_offsets"])
+                assert e2.copy_to_host(view.d_vertices, 24 * view.n_vertices).tobytes() == f["vertices"].tobytes()
+            else:
+                t2, o2 = e2.read_triangles()
+                assert t2.tobytes() == f["triangles"].tobytes() and np.array_equal(o2, f["tri_offsets"])
+                assert e2.copy_to_host(view.d_triangles, 76 * view.n_triangles).tobytes() == f["triangles"].tobytes()
+            (tmp_path / "bad").write_bytes(b"VTCHUNK1" + b"\0" * 40)
+            with pytest.raises(vt.VtmcError) as err:
+                e2.chunk_read(tmp_path / "bad")
+            assert err.value.code == -1
+    finally:
+        ex.set_output_mode(False)

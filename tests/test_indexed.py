@@ -108,6 +108,10 @@ def test_gpu_indexed_config_256(ex, oracle_mod):
     try:
         ex.set_output_mode(True)
         nv, T = check_against_oracle(ex, oracle_mod, g)
+        # per-volume {vertices, triangles} (the all-gathered array) carries WELDED vertex counts in this mode
+        _, _, vc_ptr = ex.device_results()
+        vc = ex.copy_u32(vc_ptr, 2)
+        assert (int(vc[0]), int(vc[1])) == (nv, T)
     finally:
         ex.set_output_mode(False)
     assert T == 2655156

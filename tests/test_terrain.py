@@ -170,6 +170,17 @@ def test_gpu_terrain_errors():
         with pytest.raises(vt.VtmcError) as e:
             ex.terrain_init(1032, 16, 16)
         assert e.value.code == -2 and "too high resolution" in str(e.value)        # VoxelTerrain.cs:141-142
+        # a malformed (inverted, saturating) AABB is an empty range -- the reference's loops would not
+        # execute (VoxelTerrain.cs:284-286) -- never a wrapped extent that launches out of bounds
+        ex.terrain_init(32, 16, 32, 1.0, (0.0, 0.0, 0.0), 5)
+        before = ex.terrain_read_samples().copy()
+        m = vt.SphereModifier((10.0, 8.0, 10.0), 4.0, True).to_struct()
+        for k in range(3):
+            m.lower[k] = 5.0
+            m.upper[k] = -3.0e9
+        n_dirty, T = ex.terrain_update([m])
+        assert n_dirty == 0 and T == 0
+        assert np.array_equal(ex.terrain_read_samples(), before)
 
 
 def test_oracle_heightmap_modifier_known_answer(oracle_mod):

@@ -34,7 +34,11 @@ SYMBOLS = [
     "vtmc_terrain_init", "vtmc_terrain_update", "vtmc_terrain_dirty_blocks", "vtmc_terrain_read_samples",
     "vtmc_terrain_device_grid", "vtmc_copy_volume_counts_device", "vtmc_density_fill_device_async",
     "vtmc_set_output_mode", "vtmc_last_vertex_count", "vtmc_read_indexed_mesh", "vtmc_device_indexed_results",
+    "vtmc_comm_unique_id", "vtmc_comm_init_rank", "vtmc_comm_destroy", "vtmc_allgather_volume_counts",
+    "vtmc_copy_to_host", "vtmc_chunk_write", "vtmc_chunk_read",
+    "vtmc_extract_volumes_device_async", "vtmc_extract_finish", "vtmc_last_fill_ms",
 ]
+COMM_ID_BYTES = 128
 
 MOD_PLANE, MOD_SPHERE, MOD_CYLINDER, MOD_HEIGHTMAP = 0, 1, 2, 3
 
@@ -52,6 +56,14 @@ class VolumeBatch(ctypes.Structure):
                 ("nz", ctypes.c_int32), ("stride_x", ctypes.c_int64), ("stride_y", ctypes.c_int64),
                 ("stride_z", ctypes.c_int64), ("n_volumes", ctypes.c_int32),
                 ("volume_stride", ctypes.c_int64)]
+
+
+class ChunkView(ctypes.Structure):
+    """vtmc_chunk_view: device pointers into an uploaded chunk-file image."""
+    _fields_ = [("origin", ctypes.c_int32 * 3), ("cells", ctypes.c_int32 * 3), ("flags", ctypes.c_uint32),
+                ("n_blocks", ctypes.c_uint32), ("n_triangles", ctypes.c_uint32), ("n_vertices", ctypes.c_uint32),
+                ("d_samples", ctypes.c_void_p), ("d_tri_offsets", ctypes.c_void_p), ("d_triangles", ctypes.c_void_p),
+                ("d_vert_offsets", ctypes.c_void_p), ("d_vertices", ctypes.c_void_p), ("d_indices", ctypes.c_void_p)]
 
 
 class DensityParams(ctypes.Structure):
@@ -99,6 +111,9 @@ def load():
     L.vtmc_read_cases.argtypes = [vp, vp, i64]
     L.vtmc_last_counts.argtypes = [vp, P(i32), P(i32)]
     L.vtmc_extract_volumes_device.argtypes = [vp, P(VolumeBatch), vp, u32, P(i64)]
+    L.vtmc_extract_volumes_device_async.argtypes = [vp, P(VolumeBatch), vp, u32]
+    L.vtmc_extract_finish.argtypes = [vp, P(i64)]
+    L.vtmc_last_fill_ms.argtypes = [vp, P(ctypes.c_float)]
     L.vtmc_device_results.argtypes = [vp, P(vp), P(vp), P(vp)]
     L.vtmc_reserve_triangles.argtypes = [vp, i64]
     L.vtmc_copy_volume_counts_device.argtypes = [vp, vp, i32, vp]
@@ -116,6 +131,13 @@ def load():
     L.vtmc_terrain_dirty_blocks.argtypes = [vp, vp, i32, P(i32)]
     L.vtmc_terrain_read_samples.argtypes = [vp, vp, i64, i64, i64]
     L.vtmc_terrain_device_grid.argtypes = [vp, P(vp), P(i64 * 3), P(i32 * 3)]
+    L.vtmc_comm_unique_id.argtypes = [vp]
+    L.vtmc_comm_init_rank.argtypes = [vp, vp, i32, i32]
+    L.vtmc_comm_destroy.argtypes = [vp]
+    L.vtmc_allgather_volume_counts.argtypes = [vp, vp, i32, vp]
+    L.vtmc_copy_to_host.argtypes = [vp, vp, vp, i64, vp]
+    L.vtmc_chunk_write.argtypes = [vp, ctypes.c_char_p, i32, P(i32 * 3), i32]
+    L.vtmc_chunk_read.argtypes = [vp, ctypes.c_char_p, P(ChunkView)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int:

@@ -5,15 +5,18 @@ box.  -ffp-contract=off keeps every FP32 expression a single IEEE operation sequ
 oracle is compiled the same way), so positions and normals normally agree bit for bit and the
 1e-5 bar of the north-star is met with a wide margin.
 """
+import fcntl
 import os
 import shutil
 import subprocess
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvtmc.so")
-SOURCES = ["vtmc_api.hip", "classify_kernels.hip", "emit_kernels.hip", "sweep_kernels.hip", "terrain.hip", "density.hip"]
-HEADERS = ["vtmc_internal.h", "mc_device.h", "emit_device.h", "mc_tables_packed.h", os.path.join("..", "..", "include", "vtmc.h")]
+SOURCES = ["vtmc_api.hip", "classify_kernels.hip", "emit_kernels.hip", "terrain.hip", "density.hip",
+           "chunk_io.hip", "comm.hip"]
+HEADERS = ["vtmc_internal.h", "vtmc_ctx.h", "mc_device.h", "emit_device.h", "mc_tables_packed.h", os.path.join("..", "..", "include", "vtmc.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
 
@@ -27,15 +30,30 @@ def is_stale():
 
 
 def build(force=False, verbose=False):
+    """Compiles to a unique temporary next to the target and renames it into place under a file lock:
+    every rank of a torchrun job calls this, and a rank must never dlopen a half-written library."""
     if not force and not is_stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libvtmc.so (there is no CPU fallback)")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():   # another process built it while this one waited
+                return LIB
+            tmpdir = tempfile.mkdtemp(prefix=".build-", dir=HERE)   # hipcc's offload-bundle temporaries stay in here
+            try:
+                tmp = os.path.join(tmpdir, "libvtmc.so")
+                cmd = [hipcc] + FLAGS + ["-ldl", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, LIB)
+            finally:
+                shutil.rmtree(tmpdir, ignore_errors=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

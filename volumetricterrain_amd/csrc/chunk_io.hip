@@ -1,0 +1,218 @@
+// chunk_io.hip -- persisted chunk format on the device side: one chunk of the
+// last extract is packed INTO ITS FILE IMAGE by device kernels (strided samples -> x fastest, block
+// offsets and `block` ids rebased to the chunk, mesh sections 16-byte aligned), crosses PCIe once and
+// is written with one fwrite; reading uploads the image once and hands out device pointers to its
+// sections, so the samples can be re-extracted in place.  Layout = volumetricterrain_amd/chunkfile.py.
+// New in the build: the reference keeps its grid in memory only and regenerates it from the seed
+// (Unity-Project/Assets/Scripts/VoxelTerrain.cs:145-149, TerrainEngine.cs:56-59).
+#include "vtmc_ctx.h"
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+using namespace vtmc;
+
+namespace {
+
+constexpr uint32_t kFlagSamples = 1, kFlagSoup = 2, kFlagIndexed = 4;
+
+struct __attribute__((packed)) ChunkHeader {
+    char magic[8];
+    uint32_t version, flags;
+    int32_t origin[3], cells[3];
+    uint32_t n_blocks, n_triangles, n_vertices;
+    uint8_t reserved[12];
+};
+static_assert(sizeof(ChunkHeader) == 64, "chunk header is 64 bytes (chunkfile.py HEADER)");
+
+size_t pad16(size_t n) { return (n + 15) & ~(size_t)15; }
+
+struct ChunkLayout {
+    size_t samples = 0, tri_offsets = 0, triangles = 0, vert_offsets = 0, vertices = 0, indices = 0, total = 0;
+};
+
+ChunkLayout layout_of(const ChunkHeader &h)
+{
+    ChunkLayout l;
+    size_t pos = sizeof(ChunkHeader);
+    if (h.flags & kFlagSamples) {
+        l.samples = pos;
+        pos = pad16(pos + sizeof(float) * (size_t)(h.cells[0] + 2) * (h.cells[1] + 2) * (h.cells[2] + 2));
+    }
+    l.tri_offsets = pos;
+    pos = pad16(pos + sizeof(uint32_t) * ((size_t)h.n_blocks + 1));
+    if (h.flags & kFlagSoup) {
+        l.triangles = pos;
+        pos = pad16(pos + sizeof(vtmc_triangle) * (size_t)h.n_triangles);
+    }
+    if (h.flags & kFlagIndexed) {
+        l.vert_offsets = pos;
+        pos = pad16(pos + sizeof(uint32_t) * ((size_t)h.n_blocks + 1));
+        l.vertices = pos;
+        pos = pad16(pos + sizeof(vtmc_vertex) * (size_t)h.n_vertices);
+        l.indices = pos;
+        pos += sizeof(int32_t) * 3 * (size_t)h.n_triangles;  // last section: not padded (chunkfile.py)
+    }
+    l.total = pos;
+    return l;
+}
+
+// samples of one volume, any strides -> x fastest, lane = x (coalesced on the write side always, on the
+// read side when stride_x == 1)
+__global__ __launch_bounds__(256) void pack_samples_kernel(const float *__restrict__ src, long long sx, long long sy, long long sz,
+                                                            int dx, int dy, int dz, float *__restrict__ dst)
+{
+    const long long n = (long long)dx * dy * dz;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % dx);
+        const long long t = i / dx;
+        const int y = (int)(t % dy), z = (int)(t / dy);
+        dst[i] = src[x * sx + y * sy + z * sz];
+    }
+}
+
+// dst[i] = src[i] - src[0], i in [0, n]
+__global__ __launch_bounds__(256) void pack_offsets_kernel(const uint32_t *__restrict__ src, int n_plus_1, uint32_t *__restrict__ dst)
+{
+    const uint32_t base = src[0];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_plus_1; i += gridDim.x * 256) dst[i] = src[i] - base;
+}
+
+// dword copy of n_tris 76-byte records with the `block` field (dword 18) rebased to the chunk
+__global__ __launch_bounds__(256) void pack_triangles_kernel(const uint32_t *__restrict__ src, long long n_dwords, uint32_t block_base,
+                                                              uint32_t *__restrict__ dst)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_dwords; i += (long long)gridDim.x * 256) {
+        uint32_t v = src[i];
+        if (i % 19 == 18) v -= block_base;
+        dst[i] = v;
+    }
+}
+
+int grid_for(long long n) { return (int)std::min<long long>((n + 255) / 256, 256 * 8); }
+
+}  // namespace
+
+extern "C" {
+
+int32_t vtmc_chunk_write(vtmc_ctx *ctx, const char *path, int32_t volume, const int32_t origin[3], int32_t with_samples)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!path || !origin) return fail(ctx, VTMC_ERR_INVALID_ARG, "path or origin is null");
+    if (!ctx->has_result) return fail(ctx, VTMC_ERR_NO_RESULT, "chunk_write before any extract");
+    const BlockSpace &sp = ctx->last_space;
+    if (sp.list || ctx->last_volumes <= 0) return fail(ctx, VTMC_ERR_NO_RESULT, "chunk_write needs an extract over whole volumes (not a block list)");
+    if (volume < 0 || volume >= ctx->last_volumes) return fail(ctx, VTMC_ERR_INVALID_ARG, "volume %d outside [0,%d)", volume, ctx->last_volumes);
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int bpv = sp.bpv;
+    const long long b0 = (long long)volume * bpv;
+    // the chunk's slice of the batch: offsets[b0], offsets[b0 + bpv] (and the vertex twins)
+    uint32_t span[4] = {0, 0, 0, 0};
+    VTMC_HIP(ctx, hipMemcpyAsync(&span[0], (const uint32_t *)ctx->offsets.p + b0, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    VTMC_HIP(ctx, hipMemcpyAsync(&span[1], (const uint32_t *)ctx->offsets.p + b0 + bpv, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (ctx->last_indexed) {
+        VTMC_HIP(ctx, hipMemcpyAsync(&span[2], (const uint32_t *)ctx->voffsets.p + b0, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        VTMC_HIP(ctx, hipMemcpyAsync(&span[3], (const uint32_t *)ctx->voffsets.p + b0 + bpv, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
+    VTMC_HIP(ctx, hipStreamSynchronize(st));
+
+    ChunkHeader h{};
+    memcpy(h.magic, "VTCHUNK1", 8);
+    h.version = 1;
+    h.flags = (with_samples ? kFlagSamples : 0u) | (ctx->last_indexed ? kFlagIndexed : kFlagSoup);
+    for (int k = 0; k < 3; ++k) h.origin[k] = origin[k];
+    h.cells[0] = sp.nbx * 8;
+    h.cells[1] = sp.nby * 8;
+    h.cells[2] = sp.nbz * 8;
+    h.n_blocks = (uint32_t)bpv;
+    h.n_triangles = span[1] - span[0];
+    h.n_vertices = ctx->last_indexed ? span[3] - span[2] : 0u;
+    const ChunkLayout l = layout_of(h);
+    if (int rc = ensure(ctx, ctx->chunk_image, l.total)) return rc;
+    char *img = (char *)ctx->chunk_image.p;
+    VTMC_HIP(ctx, hipMemsetAsync(img, 0, l.total, st));  // padding bytes are zero, as chunkfile.py writes them
+    VTMC_HIP(ctx, hipMemcpyAsync(img, &h, sizeof h, hipMemcpyHostToDevice, st));
+    if (with_samples) {
+        const int dx = h.cells[0] + 2, dy = h.cells[1] + 2, dz = h.cells[2] + 2;
+        const long long n = (long long)dx * dy * dz;
+        hipLaunchKernelGGL(pack_samples_kernel, dim3(grid_for(n)), dim3(256), 0, st, sp.base + volume * sp.sv, sp.sx, sp.sy, sp.sz, dx, dy,
+                           dz, (float *)(img + l.samples));
+    }
+    hipLaunchKernelGGL(pack_offsets_kernel, dim3(grid_for(bpv + 1)), dim3(256), 0, st, (const uint32_t *)ctx->offsets.p + b0, bpv + 1,
+                       (uint32_t *)(img + l.tri_offsets));
+    if (ctx->last_indexed) {
+        hipLaunchKernelGGL(pack_offsets_kernel, dim3(grid_for(bpv + 1)), dim3(256), 0, st, (const uint32_t *)ctx->voffsets.p + b0, bpv + 1,
+                           (uint32_t *)(img + l.vert_offsets));
+        if (h.n_vertices)
+            VTMC_HIP(ctx, hipMemcpyAsync(img + l.vertices, (const vtmc_vertex *)ctx->verts.p + span[2], sizeof(vtmc_vertex) * (size_t)h.n_vertices,
+                                         hipMemcpyDeviceToDevice, st));
+        if (h.n_triangles)
+            VTMC_HIP(ctx, hipMemcpyAsync(img + l.indices, (const int32_t *)ctx->indices.p + 3 * (size_t)span[0],
+                                         sizeof(int32_t) * 3 * (size_t)h.n_triangles, hipMemcpyDeviceToDevice, st));
+    } else if (h.n_triangles) {
+        const long long nd = 19ll * h.n_triangles;
+        hipLaunchKernelGGL(pack_triangles_kernel, dim3(grid_for(nd)), dim3(256), 0, st, (const uint32_t *)ctx->tris.p + 19ll * span[0], nd,
+                           (uint32_t)b0, (uint32_t *)(img + l.triangles));
+    }
+    VTMC_HIP(ctx, hipGetLastError());
+    std::vector<char> host(l.total);
+    VTMC_HIP(ctx, hipMemcpyAsync(host.data(), img, l.total, hipMemcpyDeviceToHost, st));
+    VTMC_HIP(ctx, hipStreamSynchronize(st));
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(ctx, VTMC_ERR_INVALID_ARG, "cannot open %s for writing: %s", path, strerror(errno));
+    const size_t w = fwrite(host.data(), 1, l.total, f);
+    const int cl = fclose(f);
+    if (w != l.total || cl != 0) return fail(ctx, VTMC_ERR_INVALID_ARG, "short write to %s: %s", path, strerror(errno));
+    return VTMC_OK;
+}
+
+int32_t vtmc_chunk_read(vtmc_ctx *ctx, const char *path, vtmc_chunk_view *out)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!path || !out) return fail(ctx, VTMC_ERR_INVALID_ARG, "path or out is null");
+    memset(out, 0, sizeof *out);
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(ctx, VTMC_ERR_INVALID_ARG, "cannot open %s: %s", path, strerror(errno));
+    std::vector<char> host;
+    ChunkHeader h{};
+    bool ok = fread(&h, 1, sizeof h, f) == sizeof h && memcmp(h.magic, "VTCHUNK1", 8) == 0 && h.version == 1;
+    ok = ok && h.cells[0] > 0 && h.cells[1] > 0 && h.cells[2] > 0 && h.cells[0] % 8 == 0 && h.cells[1] % 8 == 0 && h.cells[2] % 8 == 0 &&
+         (long long)h.n_blocks == (long long)(h.cells[0] / 8) * (h.cells[1] / 8) * (h.cells[2] / 8);
+    ChunkLayout l;
+    if (ok) {
+        l = layout_of(h);
+        host.resize(l.total);
+        memcpy(host.data(), &h, sizeof h);
+        ok = fread(host.data() + sizeof h, 1, l.total - sizeof h, f) == l.total - sizeof h;
+    }
+    fclose(f);
+    if (!ok) return fail(ctx, VTMC_ERR_INVALID_ARG, "%s is not a complete version-1 chunk file", path);
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    VTMC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // nothing queued may still use the previous image
+    if (int rc = ensure(ctx, ctx->chunk_image, l.total)) return rc;
+    VTMC_HIP(ctx, hipMemcpy(ctx->chunk_image.p, host.data(), l.total, hipMemcpyHostToDevice));
+    const char *img = (const char *)ctx->chunk_image.p;
+    for (int k = 0; k < 3; ++k) {
+        out->origin[k] = h.origin[k];
+        out->cells[k] = h.cells[k];
+    }
+    out->flags = h.flags;
+    out->n_blocks = h.n_blocks;
+    out->n_triangles = h.n_triangles;
+    out->n_vertices = h.n_vertices;
+    out->d_samples = (h.flags & kFlagSamples) ? (const float *)(img + l.samples) : nullptr;
+    out->d_tri_offsets = (const uint32_t *)(img + l.tri_offsets);
+    out->d_triangles = (h.flags & kFlagSoup) ? (const vtmc_triangle *)(img + l.triangles) : nullptr;
+    if (h.flags & kFlagIndexed) {
+        out->d_vert_offsets = (const uint32_t *)(img + l.vert_offsets);
+        out->d_vertices = (const vtmc_vertex *)(img + l.vertices);
+        out->d_indices = (const int32_t *)(img + l.indices);
+    }
+    return VTMC_OK;
+}
+
+}  // extern "C"

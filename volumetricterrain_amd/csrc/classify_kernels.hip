@@ -212,27 +212,34 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const uint32_t *__rest
     }
 }
 
+// The running total is kept in 64 bits: a batch may hold up to 2^31-1 blocks of up to 2560 triangles,
+// so T can pass 2^32 and a 32-bit carry would wrap to a small, plausible-looking count.  totals[0]
+// saturates at 0xFFFFFFFF in that case (the host turns any T > 2^31-1 into VTMC_ERR_TOO_LARGE, the
+// emit kernel refuses to run because no capacity reaches it); totals[2..3] hold the exact 64-bit T.
 __global__ __launch_bounds__(256) void scan_spine_kernel(uint32_t *__restrict__ partials, int n_tiles,
                                                           uint32_t *__restrict__ totals)
 {
     __shared__ uint32_t s_w[2][4];
-    uint32_t carry_s = 0, carry_a = 0;
+    unsigned long long carry_s = 0;
+    uint32_t carry_a = 0;
     for (int start = 0; start < n_tiles; start += 256) {
         int i = start + threadIdx.x;
-        uint32_t s = i < n_tiles ? partials[2 * i] : 0u;
+        uint32_t s = i < n_tiles ? partials[2 * i] : 0u;   // <= 2048 * 2560 per tile: 256 of them fit 32 bits
         uint32_t a = i < n_tiles ? partials[2 * i + 1] : 0u;
         uint32_t is = s, ia = a, ts, ta;
         wg_incl_scan2(is, ia, ts, ta, &s_w);
         if (i < n_tiles) {
-            partials[2 * i] = carry_s + is - s;  // exclusive
+            partials[2 * i] = (uint32_t)carry_s + is - s;  // exclusive (meaningless once T overflows: nothing is emitted then)
             partials[2 * i + 1] = carry_a + ia - a;
         }
         carry_s += ts;
         carry_a += ta;
     }
     if (threadIdx.x == 0) {
-        totals[0] = carry_s;  // T
-        totals[1] = carry_a;  // number of non-empty blocks
+        totals[0] = carry_s > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)carry_s;  // T, saturating
+        totals[1] = carry_a;                                                     // number of non-empty blocks
+        totals[2] = (uint32_t)carry_s;
+        totals[3] = (uint32_t)(carry_s >> 32);
     }
 }
 
@@ -268,13 +275,17 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restr
     }
 }
 
-__global__ void volume_counts_kernel(const uint32_t *__restrict__ offsets, int bpv, int n_volumes,
-                                     uint32_t *__restrict__ volume_counts)
+// Per-volume {vertices, triangles} -- the array a multi-GPU caller all-gathers.  Soup:
+// 3 unique vertices per triangle (VoxelTerrain.cs:456-459); indexed: the welded vertex count of the
+// volume's blocks, from the second scan.
+__global__ void volume_counts_kernel(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ voffsets_or_null,
+                                     int bpv, int n_volumes, uint32_t *__restrict__ volume_counts)
 {
     int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v < n_volumes) {
-        uint32_t t = offsets[(long long)(v + 1) * bpv] - offsets[(long long)v * bpv];
-        volume_counts[2 * v] = 3u * t;  // unindexed soup: 3 vertices per triangle (VoxelTerrain.cs:456-459)
+        const long long lo = (long long)v * bpv, hi = (long long)(v + 1) * bpv;
+        const uint32_t t = offsets[hi] - offsets[lo];
+        volume_counts[2 * v] = voffsets_or_null ? voffsets_or_null[hi] - voffsets_or_null[lo] : 3u * t;
         volume_counts[2 * v + 1] = t;
     }
 }
@@ -311,16 +322,21 @@ hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, u
 }
 
 hipError_t launch_scan(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list,
-                       uint32_t *partials, uint32_t *totals, int bpv, int n_volumes,
-                       uint32_t *volume_counts, hipStream_t stream)
+                       uint32_t *partials, uint32_t *totals, hipStream_t stream)
 {
     int n_tiles = (n_blocks + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, partials);
     hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(256), 0, stream, partials, n_tiles, totals);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, partials, offsets,
                        active_list);
+    return hipGetLastError();
+}
+
+hipError_t launch_volume_counts(const uint32_t *offsets, const uint32_t *voffsets_or_null, int bpv, int n_volumes,
+                                uint32_t *volume_counts, hipStream_t stream)
+{
     if (volume_counts && n_volumes > 0)
-        hipLaunchKernelGGL(volume_counts_kernel, dim3((n_volumes + 255) / 256), dim3(256), 0, stream, offsets, bpv,
+        hipLaunchKernelGGL(volume_counts_kernel, dim3((n_volumes + 255) / 256), dim3(256), 0, stream, offsets, voffsets_or_null, bpv,
                            n_volumes, volume_counts);
     return hipGetLastError();
 }

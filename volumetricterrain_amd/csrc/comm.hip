@@ -1,0 +1,165 @@
+// comm.hip -- the one collective of the path, behind the C ABI: an RCCL all-gather of the per-chunk
+// {vertex count, triangle count} pairs over xGMI.  New in the build: the reference is
+// single-process, single-GPU and has no collective call site; the call belongs where BatchUpdate
+// hands its results to the host (Unity-Project/Assets/Scripts/VoxelTerrain.cs:426-446), which a
+// multi-GPU host does once per rank.
+//
+// librccl is bound at run time (dlopen of the SONAME, so a process that already maps an RCCL -- e.g.
+// the one bundled with PyTorch -- shares it and its HIP runtime): a single-GPU host never loads it,
+// and a host without RCCL gets VTMC_ERR_DEVICE from vtmc_comm_init_rank instead of a load failure.
+// No density or mesh data ever crosses GPUs; the message is 8 bytes per chunk.
+#include "vtmc_ctx.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+
+using namespace vtmc;
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+RcclApi g_rccl;
+std::once_flag g_rccl_once;
+
+const RcclApi &rccl()
+{
+    std::call_once(g_rccl_once, [] {
+        RcclApi &a = g_rccl;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.handle) break;
+        }
+        if (!a.handle) {
+            const char *e = dlerror();
+            a.error = std::string("cannot load librccl.so.1: ") + (e ? e : "unknown error");
+            return;
+        }
+        a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.handle, "ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
+        a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
+        a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
+        a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+        if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString) {
+            a.error = "librccl.so.1 lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+            a.handle = nullptr;
+        }
+    });
+    return g_rccl;
+}
+
+#define VTMC_NCCL(ctx, api, expr)                                                                                \
+    do {                                                                                                         \
+        ncclResult_t r_ = (expr);                                                                                \
+        if (r_ != ncclSuccess)                                                                                   \
+            return fail(ctx, VTMC_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, (api).GetErrorString(r_), __FILE__, \
+                        __LINE__);                                                                               \
+    } while (0)
+
+}  // namespace
+
+namespace vtmc {
+void comm_release(vtmc_ctx *ctx)
+{
+    if (ctx && ctx->comm) {
+        const RcclApi &a = rccl();
+        if (a.handle) (void)a.CommDestroy((ncclComm_t)ctx->comm);
+        ctx->comm = nullptr;
+        ctx->comm_world = 1;
+        ctx->comm_rank = 0;
+    }
+}
+}  // namespace vtmc
+
+extern "C" {
+
+int32_t vtmc_comm_unique_id(uint8_t id[VTMC_COMM_ID_BYTES])
+{
+    if (!id) return fail(nullptr, VTMC_ERR_INVALID_ARG, "id is null");
+    static_assert(VTMC_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "vtmc.h and rccl.h disagree on the unique-id size");
+    const RcclApi &a = rccl();
+    if (!a.handle) return fail(nullptr, VTMC_ERR_DEVICE, "%s", a.error.c_str());
+    ncclUniqueId u;
+    VTMC_NCCL(nullptr, a, a.GetUniqueId(&u));
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return VTMC_OK;
+}
+
+int32_t vtmc_comm_init_rank(vtmc_ctx *ctx, const uint8_t id[VTMC_COMM_ID_BYTES], int32_t rank, int32_t world_size)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!id) return fail(ctx, VTMC_ERR_INVALID_ARG, "id is null");
+    if (world_size <= 0 || rank < 0 || rank >= world_size) return fail(ctx, VTMC_ERR_INVALID_ARG, "bad rank %d / world %d", rank, world_size);
+    const RcclApi &a = rccl();
+    if (!a.handle) return fail(ctx, VTMC_ERR_DEVICE, "%s", a.error.c_str());
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    comm_release(ctx);
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t c = nullptr;
+    VTMC_NCCL(ctx, a, a.CommInitRank(&c, world_size, u, rank));
+    ctx->comm = c;
+    ctx->comm_rank = rank;
+    ctx->comm_world = world_size;
+    return VTMC_OK;
+}
+
+int32_t vtmc_comm_destroy(vtmc_ctx *ctx)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (ctx->stream) VTMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    comm_release(ctx);
+    return VTMC_OK;
+}
+
+int32_t vtmc_allgather_volume_counts(vtmc_ctx *ctx, uint32_t *d_all_counts, int32_t volumes_per_rank, void *stream)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->comm) return fail(ctx, VTMC_ERR_NO_RESULT, "allgather_volume_counts before vtmc_comm_init_rank");
+    // the counts are final once the scan has run: valid for a finished extract and for a queued one
+    // (vtmc_extract_volumes_device_async), which is how a rank keeps its host out of the step
+    if (!ctx->has_result && !ctx->pending.active) return fail(ctx, VTMC_ERR_NO_RESULT, "allgather_volume_counts before any extract");
+    const int n_vol = ctx->pending.active ? ctx->pending.n_volumes : ctx->last_volumes;
+    const int n_blk = ctx->pending.active ? ctx->pending.sp.n_blocks : ctx->last_blocks;
+    if (!d_all_counts) return fail(ctx, VTMC_ERR_INVALID_ARG, "d_all_counts is null");
+    if (volumes_per_rank < n_vol || volumes_per_rank <= 0)
+        return fail(ctx, VTMC_ERR_CAPACITY, "volumes_per_rank %d < %d volumes of the last extract", volumes_per_rank, n_vol);
+    const RcclApi &a = rccl();
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    // ranks may own different numbers of chunks (c % N): every rank sends volumes_per_rank pairs, zero-padded
+    const size_t words = 2 * (size_t)volumes_per_rank;
+    if (ctx->comm_send.bytes < words * sizeof(uint32_t)) VTMC_HIP(ctx, hipStreamSynchronize(st));  // about to reallocate
+    if (int rc = ensure(ctx, ctx->comm_send, words * sizeof(uint32_t))) return rc;
+    const size_t own = 2 * (size_t)(n_blk > 0 ? n_vol : 0);
+    if (own < words) VTMC_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->comm_send.p + own, 0, (words - own) * sizeof(uint32_t), st));
+    if (own > 0)
+        VTMC_HIP(ctx, hipMemcpyAsync(ctx->comm_send.p, ctx->volcounts.p, own * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    VTMC_NCCL(ctx, a, a.AllGather(ctx->comm_send.p, d_all_counts, words, ncclUint32, (ncclComm_t)ctx->comm, st));
+    return VTMC_OK;
+}
+
+int32_t vtmc_copy_to_host(vtmc_ctx *ctx, const void *d_src, void *dst, int64_t bytes, void *stream)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (bytes < 0 || (bytes > 0 && (!d_src || !dst))) return fail(ctx, VTMC_ERR_INVALID_ARG, "null pointer or negative size");
+    if (bytes == 0) return VTMC_OK;
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    VTMC_HIP(ctx, hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, st));
+    VTMC_HIP(ctx, hipStreamSynchronize(st));
+    return VTMC_OK;
+}
+
+}  // extern "C"

@@ -1,5 +1,5 @@
-// emit_device.h -- device code shared by the kernels that emit triangles (emit_kernels.hip: one wave
-// per non-empty block after the scan; sweep_kernels.hip: the single-pass kernel): lattice normals
+// emit_device.h -- device code of the kernels that emit triangles (emit_kernels.hip: one wave per
+// non-empty block after the scan): lattice normals
 // (Shaders/SampleNormal.compute:27-33), edge vertices and the trilinear normal fetch
 // (Shaders/MarchingCube.compute:69-99, 128-133), triangle records (MarchingCube.compute:143-162).
 #ifndef VTMC_EMIT_DEVICE_H
@@ -11,7 +11,7 @@ namespace vtmc {
 constexpr int kTriDwords = 19;     // 76-byte record
 
 // ----------------------------------------------------------------------------------------------
-// Per-block emit, shared by emit_kernel and sweep_kernel:
+// Per-block emit:
 //   * pass 1 classifies (8 unrolled layers) and compacts the ACTIVE cells with one ballot per layer;
 //   * pass 2 runs the triangle-slot prefix sum over 64 active cells at a time; a slot carries the
 //     cell and the triangle's three edge ids, read from the packed table once per CELL;

@@ -10,9 +10,8 @@
 //    the emit kernel itself refuses to run past the triangle buffer's capacity, in which case the
 //    buffer is grown and only the emit stage is queued again;
 //  * no CPU fallback of any kind: without a HIP device vtmc_create fails.
-#include "../../include/vtmc.h"
 #include "mc_tables_packed.h"
-#include "vtmc_internal.h"
+#include "vtmc_ctx.h"
 
 #include <algorithm>
 #include <climits>
@@ -25,52 +24,13 @@
 #include <vector>
 
 using namespace vtmc;
+typedef VtmcDevBuf DevBuf;
 
 namespace {
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-};
-
 thread_local std::string g_create_error;
-
 }  // namespace
 
-struct vtmc_ctx {
-    int device = 0;
-    int n_cus = 256;
-    hipStream_t stream = nullptr;
-    DeviceTables tables{nullptr, nullptr};
-    DevBuf d_vert, d_trinum;
-    DevBuf counts, offsets, active, partials, totals, volcounts, cases, tris, input, list, perm, origins, sweep;
-    DevBuf vcounts, voffsets, vpartials, vtotals, verts, indices;  // indexed output
-    int output_mode = VTMC_OUTPUT_SOUP;
-    bool last_indexed = false;
-    int64_t last_verts = 0;
-    uint32_t *h_totals = nullptr;  // pinned: {T, nActive} of the scan, or the sweep kernel's kCtrlWords control words
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0..3] stage timing, [4] staging copies
-    float stage_ms[4] = {0, 0, 0, 0};
-    // last result
-    bool has_result = false;
-    BlockSpace last_space{};
-    int last_blocks = 0;
-    int last_volumes = 0;
-    int64_t last_tris = 0;
-    Tuning tune;
-    // device-resident terrain (vtmc_terrain_*)
-    DevBuf terrain, heightmap;
-    TerrainShape tshape{};
-    bool has_terrain = false;
-    uint32_t terrain_events = 0;
-    std::vector<int32_t> dirty;  // (bx,by,bz) of the last vtmc_terrain_update, ordered by block id
-    bool dirty_is_all = false;   // ... or every block (the list is then materialised on demand only)
-    uint64_t perm_seed = 0;
-    bool perm_valid = false;
-    std::string err;
-};
-
-namespace {
+namespace vtmc {
 
 int fail(vtmc_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -84,13 +44,7 @@ int fail(vtmc_ctx *ctx, int code, const char *fmt, ...)
     return code;
 }
 
-#define VTMC_HIP(ctx, expr)                                                                          \
-    do {                                                                                             \
-        hipError_t e_ = (expr);                                                                      \
-        if (e_ != hipSuccess)                                                                        \
-            return fail(ctx, VTMC_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                        __FILE__, __LINE__);                                                         \
-    } while (0)
+const char *create_error_text() { return g_create_error.c_str(); }
 
 int ensure(vtmc_ctx *ctx, DevBuf &b, size_t bytes)
 {
@@ -111,49 +65,77 @@ void release(DevBuf &b)
     b.bytes = 0;
 }
 
-// Single pass: classify + chained scan + emit in one kernel (sweep_kernels.hip).  The kernel counts
-// every triangle but writes only those below the buffer's capacity, so a buffer that turns out too
-// small costs one more launch (the first call on a new field, typically).
-int run_sweep(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, hipStream_t stream, int64_t &T_found)
+}  // namespace vtmc
+
+namespace {
+
+// One launch of the emit stage on the pending extract's stream, followed by the asynchronous copy of
+// the scan's totals into pinned memory.  The kernel itself refuses to run past its buffers' capacity
+// (it compares the device-resident T / V with the capacities it is handed).
+int queue_emit(vtmc_ctx *ctx)
 {
-    if (int rc = ensure(ctx, ctx->sweep, sweep_scratch_bytes(sp))) return rc;
-    for (int attempt = 0;; ++attempt) {
-        const size_t cap = std::min<size_t>(ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
-        VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
-        VTMC_HIP(ctx, launch_sweep(sp, ctx->tables, ctx->sweep.p, (uint32_t *)ctx->offsets.p, cap, ctx->tris.p, ctx->n_cus, n_volumes,
-                                   (uint32_t *)ctx->volcounts.p, ctx->tune, stream));
-        VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
-        VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->sweep.p, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        VTMC_HIP(ctx, hipStreamSynchronize(stream));
-        if (ctx->h_totals[kCtrlError])
-            return fail(ctx, VTMC_ERR_DEVICE, "sweep kernel: a chained-scan wait timed out (predecessor brick never published)");
-        const uint64_t T = ((uint64_t)ctx->h_totals[kCtrlTotalHi] << 32) | ctx->h_totals[kCtrlTotalLo];
-        if (T > 0x7fffffffull) return fail(ctx, VTMC_ERR_TOO_LARGE, "%llu triangles exceed the int32 range of the ABI", (unsigned long long)T);
-        T_found = (int64_t)T;
-        if ((size_t)T <= cap) break;
-        if (attempt == 1) return fail(ctx, VTMC_ERR_DEVICE, "triangle buffer still too small after growing");
-        if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * ((size_t)T + (size_t)T / 8 + 1024))) return rc;
-    }
-    float ms = 0;
-    VTMC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]));
-    ctx->stage_ms[0] = ctx->stage_ms[3] = ms;
-    ctx->stage_ms[1] = ctx->stage_ms[2] = 0;
+    const VtmcPending &pe = ctx->pending;
+    hipStream_t stream = pe.stream;
+    const bool indexed = pe.indexed;
+    const size_t tcap = std::min<size_t>(indexed ? ctx->indices.bytes / (3 * sizeof(int32_t)) : ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
+    const size_t vcap = indexed ? std::min<size_t>(ctx->verts.bytes / sizeof(vtmc_vertex), 0x7fffffffu) : 0;
+    ctx->pending.tcap = tcap;
+    ctx->pending.vcap = vcap;
+    uint32_t *queue = (uint32_t *)ctx->totals.p + 64;
+    VTMC_HIP(ctx, hipMemsetAsync(queue, 0, kQueueWords * sizeof(uint32_t), stream));
+    if (indexed)
+        VTMC_HIP(ctx, launch_emit_indexed(pe.sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const uint32_t *)ctx->voffsets.p,
+                                          (const int32_t *)ctx->active.p, (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->vtotals.p,
+                                          (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p, ctx->indices.p, ctx->n_cus, ctx->tune, queue, stream));
+    else
+        VTMC_HIP(ctx, launch_emit(pe.sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const int32_t *)ctx->active.p,
+                                  (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->counts.p, (uint32_t)tcap, ctx->tris.p,
+                                  ctx->n_cus, ctx->tune, queue, stream));
+    VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
+    // {T saturating, nActive, T as 64 bits} -- the scan keeps its running total in 64 bits, so a batch
+    // whose triangle count passes 2^32 is reported as such instead of wrapping to a small count
+    VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->totals.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (indexed) VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 4, ctx->vtotals.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     return VTMC_OK;
 }
 
-// classify -> scan -> emit as separate kernels; `indexed` selects the welded output.  {T, nActive}
-// (and V) stay in device memory until the single read-back at the end; the emit kernel refuses to
-// run past its buffers' capacity, in which case they are grown (with head-room, so a slowly changing
-// field does not regrow every frame) and only the emit stage is queued again.
-int run_staged(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t flags, bool dense, bool indexed, hipStream_t stream,
-               int64_t &T_found, int64_t &V_found)
+// Queues the device side of BatchUpdate (VoxelTerrain.cs:365-427) -- classify -> scan -> emit -- on
+// `stream` and returns without waiting: {T, nActive} (and V) stay in device memory, there is no
+// mid-pipeline read-back (VoxelTerrain.cs:394-395).  extract_finish() completes the call.
+int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t flags, hipStream_t stream)
 {
     const int B = sp.n_blocks;
+    const bool indexed = ctx->output_mode == VTMC_OUTPUT_INDEXED;
+    ctx->has_result = false;
+    ctx->pending = VtmcPending{};
+    VtmcPending pe;
+    pe.sp = sp;
+    pe.n_volumes = n_volumes;
+    pe.indexed = indexed;
+    pe.stream = stream;
+    if (B == 0) {  // the reference's early exit (VoxelTerrain.cs:396-405): empty offsets, nothing launched
+        if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t))) return rc;
+        VTMC_HIP(ctx, hipMemsetAsync(ctx->offsets.p, 0, sizeof(uint32_t), stream));
+        if (indexed) {
+            if (int rc = ensure(ctx, ctx->voffsets, sizeof(uint32_t))) return rc;
+            VTMC_HIP(ctx, hipMemsetAsync(ctx->voffsets.p, 0, sizeof(uint32_t), stream));
+        }
+        pe.active = true;
+        ctx->pending = pe;
+        return VTMC_OK;
+    }
+    // the emit kernel addresses a tile with 32-bit byte offsets from the block origin
+    if ((9.0 * ((double)sp.sx + (double)sp.sy + (double)sp.sz) + 1.0) * 4.0 >= 4294967296.0)
+        return fail(ctx, VTMC_ERR_TOO_LARGE, "strides too large: a 10x10x10 tile must span less than 4 GiB");
     const int n_tiles = (B + kScanTile - 1) / kScanTile;
+    if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
+    if (int rc = ensure(ctx, ctx->volcounts, sizeof(uint32_t) * 2 * (size_t)std::max(n_volumes, 1))) return rc;
+    if (!indexed && !ctx->tris.p)
+        if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * ((size_t)1 << 20))) return rc;
     if (int rc = ensure(ctx, ctx->counts, sizeof(uint32_t) * (size_t)B)) return rc;
     if (int rc = ensure(ctx, ctx->active, sizeof(int32_t) * (size_t)B)) return rc;
     if (int rc = ensure(ctx, ctx->partials, sizeof(uint32_t) * 2 * (size_t)n_tiles)) return rc;
-    if (int rc = ensure(ctx, ctx->totals, sizeof(uint32_t) * (64 + kQueueWords))) return rc;  // {T, nActive}, then the emit kernel's ticket counters
+    if (int rc = ensure(ctx, ctx->totals, sizeof(uint32_t) * (64 + kQueueWords))) return rc;  // scan totals, then the emit kernel's ticket counters
     uint8_t *d_cases = nullptr;
     if (flags & VTMC_FLAG_WANT_CASES) {
         if (int rc = ensure(ctx, ctx->cases, (size_t)B * 512)) return rc;
@@ -171,101 +153,88 @@ int run_staged(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t flag
             if (int rc = ensure(ctx, ctx->indices, sizeof(int32_t) * 3 * ((size_t)1 << 20))) return rc;
         d_vcounts = (uint32_t *)ctx->vcounts.p;
     }
+    const bool dense = !sp.list && sp.sx == 1 && sp.nx >= 32 && !(flags & (VTMC_FLAG_WANT_CASES | VTMC_FLAG_NO_DENSE_PATH));
 
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
     if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_vcounts, ctx->tune.classify_ablate, stream));
     else VTMC_HIP(ctx, launch_classify_blocks(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_cases, d_vcounts, ctx->n_cus, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
     VTMC_HIP(ctx, launch_scan((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p, (int32_t *)ctx->active.p,
-                              (uint32_t *)ctx->partials.p, (uint32_t *)ctx->totals.p, sp.bpv, n_volumes, (uint32_t *)ctx->volcounts.p, stream));
+                              (uint32_t *)ctx->partials.p, (uint32_t *)ctx->totals.p, stream));
     if (indexed)  // the same scan over the welded-vertex counts: per-block vertex offsets + V
         VTMC_HIP(ctx, launch_scan(d_vcounts, B, (uint32_t *)ctx->voffsets.p, nullptr, (uint32_t *)ctx->vpartials.p,
-                                  (uint32_t *)ctx->vtotals.p, sp.bpv, 0, nullptr, stream));
+                                  (uint32_t *)ctx->vtotals.p, stream));
+    VTMC_HIP(ctx, launch_volume_counts((const uint32_t *)ctx->offsets.p, indexed ? (const uint32_t *)ctx->voffsets.p : nullptr, sp.bpv,
+                                       n_volumes, (uint32_t *)ctx->volcounts.p, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
+    pe.active = true;
+    pe.launched = true;
+    ctx->pending = pe;
+    return queue_emit(ctx);
+}
 
-    for (int attempt = 0;; ++attempt) {
-        const size_t tcap = std::min<size_t>(indexed ? ctx->indices.bytes / (3 * sizeof(int32_t)) : ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
-        const size_t vcap = indexed ? std::min<size_t>(ctx->verts.bytes / sizeof(vtmc_vertex), 0x7fffffffu) : 0;
-        uint32_t *queue = (uint32_t *)ctx->totals.p + 64;
-        VTMC_HIP(ctx, hipMemsetAsync(queue, 0, kQueueWords * sizeof(uint32_t), stream));
-        if (indexed)
-            VTMC_HIP(ctx, launch_emit_indexed(sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const uint32_t *)ctx->voffsets.p,
-                                              (const int32_t *)ctx->active.p, (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->vtotals.p,
-                                              (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p, ctx->indices.p, ctx->n_cus, ctx->tune, queue, stream));
-        else
-            VTMC_HIP(ctx, launch_emit(sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const int32_t *)ctx->active.p,
-                                      (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->counts.p, (uint32_t)tcap, ctx->tris.p,
-                                      ctx->n_cus, ctx->tune, queue, stream));
-        VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
-        VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->totals.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        if (indexed) VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 2, ctx->vtotals.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        VTMC_HIP(ctx, hipStreamSynchronize(stream));
-        const uint32_t T = ctx->h_totals[0], V = indexed ? ctx->h_totals[2] : 0u;
-        if (T > 0x7fffffffu || V > 0x7fffffffu)
-            return fail(ctx, VTMC_ERR_TOO_LARGE, "%u triangles / %u vertices exceed the int32 range of the ABI", T, V);
-        T_found = T;
-        V_found = V;
-        if ((size_t)T <= tcap && (size_t)V <= vcap) break;
-        if (attempt == 1) return fail(ctx, VTMC_ERR_DEVICE, "output buffers still too small after growing");
-        if ((size_t)T > tcap) {
-            const size_t want = (size_t)T + (size_t)T / 8 + 1024;
-            if (int rc = indexed ? ensure(ctx, ctx->indices, sizeof(int32_t) * 3 * want) : ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * want)) return rc;
+// Completes a queued extract: waits for the stream, reads {T, V} from pinned memory and -- when the
+// emit kernel found its buffers too small and did not run -- grows them (with head-room, so a slowly
+// changing field does not regrow every frame) and queues only the emit stage again.
+int extract_finish(vtmc_ctx *ctx, int64_t *tri_count)
+{
+    if (!ctx->pending.active) return fail(ctx, VTMC_ERR_NO_RESULT, "extract_finish without a queued extract");
+    const VtmcPending pe = ctx->pending;
+    int64_t T_found = 0, V_found = 0;
+    if (!pe.launched) {
+        memset(ctx->stage_ms, 0, sizeof ctx->stage_ms);
+        VTMC_HIP(ctx, hipStreamSynchronize(pe.stream));
+    } else {
+        for (int attempt = 0;; ++attempt) {
+            VTMC_HIP(ctx, hipStreamSynchronize(pe.stream));
+            const uint64_t T = ((uint64_t)ctx->h_totals[3] << 32) | ctx->h_totals[2];
+            const uint64_t V = pe.indexed ? (((uint64_t)ctx->h_totals[7] << 32) | ctx->h_totals[6]) : 0ull;
+            if (T > 0x7fffffffull || V > 0x7fffffffull) {
+                ctx->pending.active = false;
+                return fail(ctx, VTMC_ERR_TOO_LARGE, "%llu triangles / %llu vertices exceed the int32 range of the ABI",
+                            (unsigned long long)T, (unsigned long long)V);
+            }
+            T_found = (int64_t)T;
+            V_found = (int64_t)V;
+            if ((size_t)T <= ctx->pending.tcap && (size_t)V <= ctx->pending.vcap) break;
+            if (attempt == 1) {
+                ctx->pending.active = false;
+                return fail(ctx, VTMC_ERR_DEVICE, "output buffers still too small after growing");
+            }
+            if ((size_t)T > ctx->pending.tcap) {
+                const size_t want = (size_t)T + (size_t)T / 8 + 1024;
+                if (int rc = pe.indexed ? ensure(ctx, ctx->indices, sizeof(int32_t) * 3 * want) : ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * want)) return rc;
+            }
+            if ((size_t)V > ctx->pending.vcap)
+                if (int rc = ensure(ctx, ctx->verts, sizeof(vtmc_vertex) * ((size_t)V + (size_t)V / 8 + 1024))) return rc;
+            VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], pe.stream));
+            if (int rc = queue_emit(ctx)) return rc;
         }
-        if ((size_t)V > vcap)
-            if (int rc = ensure(ctx, ctx->verts, sizeof(vtmc_vertex) * ((size_t)V + (size_t)V / 8 + 1024))) return rc;
-        VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
+        float a = 0, b = 0, c = 0;
+        VTMC_HIP(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+        VTMC_HIP(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+        VTMC_HIP(ctx, hipEventElapsedTime(&c, ctx->ev[2], ctx->ev[3]));
+        ctx->stage_ms[0] = a;
+        ctx->stage_ms[1] = b;
+        ctx->stage_ms[2] = c;
+        ctx->stage_ms[3] = a + b + c;
     }
-    float a = 0, b = 0, c = 0;
-    VTMC_HIP(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
-    VTMC_HIP(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
-    VTMC_HIP(ctx, hipEventElapsedTime(&c, ctx->ev[2], ctx->ev[3]));
-    ctx->stage_ms[0] = a;
-    ctx->stage_ms[1] = b;
-    ctx->stage_ms[2] = c;
-    ctx->stage_ms[3] = a + b + c;
+    ctx->pending.active = false;
+    ctx->has_result = true;
+    ctx->last_space = pe.sp;
+    ctx->last_blocks = pe.sp.n_blocks;
+    ctx->last_volumes = pe.n_volumes;
+    ctx->last_tris = T_found;
+    ctx->last_verts = V_found;
+    ctx->last_indexed = pe.indexed;
+    if (tri_count) *tri_count = T_found;
     return VTMC_OK;
 }
 
-// The device side of BatchUpdate (VoxelTerrain.cs:365-427) on `stream`; fills last_* and stage_ms.
 int extract_core(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t flags, hipStream_t stream, int64_t *tri_count)
 {
-    const int B = sp.n_blocks;
-    const bool indexed = ctx->output_mode == VTMC_OUTPUT_INDEXED;
-    ctx->has_result = false;
-    int64_t T_found = 0, V_found = 0;
-    if (B == 0) {  // the reference's early exit (VoxelTerrain.cs:396-405): empty offsets, nothing launched
-        memset(ctx->stage_ms, 0, sizeof ctx->stage_ms);
-        if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t))) return rc;
-        VTMC_HIP(ctx, hipMemsetAsync(ctx->offsets.p, 0, sizeof(uint32_t), stream));
-        if (indexed) {
-            if (int rc = ensure(ctx, ctx->voffsets, sizeof(uint32_t))) return rc;
-            VTMC_HIP(ctx, hipMemsetAsync(ctx->voffsets.p, 0, sizeof(uint32_t), stream));
-        }
-        VTMC_HIP(ctx, hipStreamSynchronize(stream));
-    } else {
-        // the emit kernel addresses a tile with 32-bit byte offsets from the block origin
-        if ((9.0 * ((double)sp.sx + (double)sp.sy + (double)sp.sz) + 1.0) * 4.0 >= 4294967296.0)
-            return fail(ctx, VTMC_ERR_TOO_LARGE, "strides too large: a 10x10x10 tile must span less than 4 GiB");
-        if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
-        if (int rc = ensure(ctx, ctx->volcounts, sizeof(uint32_t) * 2 * (size_t)std::max(n_volumes, 1))) return rc;
-        if (!indexed && !ctx->tris.p)
-            if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * ((size_t)1 << 20))) return rc;
-        const bool dense = !sp.list && sp.sx == 1 && sp.nx >= 32 && !(flags & (VTMC_FLAG_WANT_CASES | VTMC_FLAG_NO_DENSE_PATH));
-        if (dense && ctx->tune.sweep && !indexed) {
-            if (int rc = run_sweep(ctx, sp, n_volumes, stream, T_found)) return rc;
-        } else {
-            if (int rc = run_staged(ctx, sp, n_volumes, flags, dense, indexed, stream, T_found, V_found)) return rc;
-        }
-    }
-    ctx->has_result = true;
-    ctx->last_space = sp;
-    ctx->last_blocks = B;
-    ctx->last_volumes = n_volumes;
-    ctx->last_tris = T_found;
-    ctx->last_verts = V_found;
-    ctx->last_indexed = indexed;
-    if (tri_count) *tri_count = T_found;
-    return VTMC_OK;
+    if (int rc = extract_queue(ctx, sp, n_volumes, flags, stream)) return rc;
+    return extract_finish(ctx, tri_count);
 }
 
 int check_dims(vtmc_ctx *ctx, int nx, int ny, int nz)
@@ -341,7 +310,9 @@ int32_t vtmc_create(int32_t device, vtmc_ctx **out_ctx)
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (auto &ev : ctx->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipHostMalloc((void **)&ctx->h_totals, kCtrlWords * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+    for (auto &ev : ctx->ev_fill)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipHostMalloc((void **)&ctx->h_totals, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
 
     // tables: VoxelTerrain.cs:151-156 uploads three int tables; here the packed 2 KB vert table and a
@@ -367,19 +338,23 @@ int32_t vtmc_destroy(vtmc_ctx *ctx)
     if (!ctx) return VTMC_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    comm_release(ctx);
     for (DevBuf *b : {&ctx->d_vert, &ctx->d_trinum, &ctx->counts, &ctx->offsets, &ctx->active, &ctx->partials, &ctx->totals,
-                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->sweep, &ctx->terrain, &ctx->heightmap,
-                      &ctx->vcounts, &ctx->voffsets, &ctx->vpartials, &ctx->vtotals, &ctx->verts, &ctx->indices})
+                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->terrain, &ctx->heightmap,
+                      &ctx->vcounts, &ctx->voffsets, &ctx->vpartials, &ctx->vtotals, &ctx->verts, &ctx->indices, &ctx->chunk_image,
+                      &ctx->comm_send})
         release(*b);
     if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
     for (auto &ev : ctx->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : ctx->ev_fill)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VTMC_OK;
 }
 
-const char *vtmc_last_error(const vtmc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *vtmc_last_error(const vtmc_ctx *ctx) { return ctx ? ctx->err.c_str() : create_error_text(); }
 
 int32_t vtmc_extract_blocks(vtmc_ctx *ctx, const float *samples, int32_t n_blocks, int32_t *tri_count)
 {
@@ -616,6 +591,29 @@ int32_t vtmc_extract_volumes_device(vtmc_ctx *ctx, const vtmc_volume_batch *batc
     return extract_core(ctx, sp, batch->n_volumes, flags, stream ? (hipStream_t)stream : ctx->stream, tri_count);
 }
 
+int32_t vtmc_extract_volumes_device_async(vtmc_ctx *ctx, const vtmc_volume_batch *batch, void *stream, uint32_t flags)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (!batch || !batch->d_samples) return fail(ctx, VTMC_ERR_INVALID_ARG, "batch or batch->d_samples is null");
+    if (int rc = check_dims(ctx, batch->nx, batch->ny, batch->nz)) return rc;
+    if (batch->n_volumes < 0) return fail(ctx, VTMC_ERR_INVALID_ARG, "n_volumes < 0");
+    if (batch->stride_x <= 0 || batch->stride_y <= 0 || batch->stride_z <= 0 || batch->volume_stride < 0)
+        return fail(ctx, VTMC_ERR_INVALID_ARG, "strides must be positive");
+    const long long bpv = (long long)(batch->nx / 8) * (batch->ny / 8) * (batch->nz / 8);
+    if (bpv * batch->n_volumes > 0x7fffffffll) return fail(ctx, VTMC_ERR_TOO_LARGE, "more than 2^31-1 blocks");
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    BlockSpace sp = dense_space(batch->d_samples, batch->nx, batch->ny, batch->nz, batch->stride_x, batch->stride_y,
+                                batch->stride_z, batch->n_volumes, batch->volume_stride);
+    return extract_queue(ctx, sp, batch->n_volumes, flags, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int32_t vtmc_extract_finish(vtmc_ctx *ctx, int64_t *tri_count)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    return extract_finish(ctx, tri_count);
+}
+
 int32_t vtmc_device_results(vtmc_ctx *ctx, const vtmc_triangle **d_triangles, const uint32_t **d_block_tri_offsets,
                             const uint32_t **d_volume_counts)
 {
@@ -630,12 +628,15 @@ int32_t vtmc_device_results(vtmc_ctx *ctx, const vtmc_triangle **d_triangles, co
 int32_t vtmc_copy_volume_counts_device(vtmc_ctx *ctx, uint32_t *d_dst, int32_t capacity_volumes, void *stream)
 {
     if (!ctx) return VTMC_ERR_INVALID_ARG;
-    if (!ctx->has_result) return fail(ctx, VTMC_ERR_NO_RESULT, "copy_volume_counts before any extract");
-    if (capacity_volumes < ctx->last_volumes) return fail(ctx, VTMC_ERR_CAPACITY, "capacity %d < %d volumes", capacity_volumes, ctx->last_volumes);
-    if (ctx->last_volumes == 0 || ctx->last_blocks == 0) return VTMC_OK;
+    // the counts are final once the scan has run: valid for a finished extract and for a queued one
+    if (!ctx->has_result && !ctx->pending.active) return fail(ctx, VTMC_ERR_NO_RESULT, "copy_volume_counts before any extract");
+    const int n_vol = ctx->pending.active ? ctx->pending.n_volumes : ctx->last_volumes;
+    const int n_blk = ctx->pending.active ? ctx->pending.sp.n_blocks : ctx->last_blocks;
+    if (capacity_volumes < n_vol) return fail(ctx, VTMC_ERR_CAPACITY, "capacity %d < %d volumes", capacity_volumes, n_vol);
+    if (n_vol == 0 || n_blk == 0) return VTMC_OK;
     if (!d_dst) return fail(ctx, VTMC_ERR_INVALID_ARG, "d_dst is null");
     VTMC_HIP(ctx, hipSetDevice(ctx->device));
-    VTMC_HIP(ctx, hipMemcpyAsync(d_dst, ctx->volcounts.p, sizeof(uint32_t) * 2 * (size_t)ctx->last_volumes, hipMemcpyDeviceToDevice,
+    VTMC_HIP(ctx, hipMemcpyAsync(d_dst, ctx->volcounts.p, sizeof(uint32_t) * 2 * (size_t)n_vol, hipMemcpyDeviceToDevice,
                                  stream ? (hipStream_t)stream : ctx->stream));
     return VTMC_OK;
 }
@@ -671,8 +672,6 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     else if (k == "emit_row_masks") ctx->tune.emit_row_masks = value;
     else if (k == "emit_group_log2") ctx->tune.emit_group_log2 = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (k == "emit_wgs_per_cu") ctx->tune.emit_wgs_per_cu = value;
-    else if (k == "sweep") ctx->tune.sweep = value;
-    else if (k == "sweep_wgs_per_cu") ctx->tune.sweep_wgs_per_cu = value;
     else return fail(ctx, VTMC_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
     return VTMC_OK;
 }
@@ -747,9 +746,18 @@ int32_t vtmc_terrain_update(vtmc_ctx *ctx, const vtmc_modifier *mods, int32_t n_
         a.lx = low[0];
         a.ly = low[1];
         a.lz = low[2];
-        a.dx = up[0] - low[0] + 1;
-        a.dy = up[1] - low[1] + 1;
-        a.dz = up[2] - low[2] + 1;
+        // extents in 64 bits: floor/ceil saturate at INT32_MIN/MAX, so an inverted or far-away AABB must
+        // come out as an empty range (the reference's loops simply do not execute, VoxelTerrain.cs:284-286),
+        // never as a wrapped positive size; low >= 0 and up <= top bound a valid extent by the grid
+        int ext[3];
+        for (int k = 0; k < 3; ++k) {
+            const long long e = (long long)up[k] - (long long)low[k] + 1;
+            ext[k] = e <= 0 ? 0 : (int)std::min<long long>(e, (long long)top[k] - low[k] + 1);
+            if (low[k] > top[k]) ext[k] = 0;
+        }
+        a.dx = ext[0];
+        a.dy = ext[1];
+        a.dz = ext[2];
         a.event = ++ctx->terrain_events;
         if (md.kind == VTMC_MOD_HEIGHTMAP && a.dx > 0 && a.dy > 0 && a.dz > 0) {
             // _heightmap (IslandModifier.cs:36) goes to the device; an earlier modifier of this queue may
@@ -928,7 +936,20 @@ int32_t vtmc_density_fill_device_async(vtmc_ctx *ctx, const vtmc_density_params 
     dl.sz = stride_z;
     dl.sv = volume_stride;
     dl.n_volumes = n_volumes;
+    VTMC_HIP(ctx, hipEventRecord(ctx->ev_fill[0], st));
     VTMC_HIP(ctx, launch_density(dl, (const unsigned char *)ctx->perm.p, (const int *)ctx->origins.p, d_out, st));
+    VTMC_HIP(ctx, hipEventRecord(ctx->ev_fill[1], st));
+    ctx->fill_timed = true;
+    return VTMC_OK;
+}
+
+int32_t vtmc_last_fill_ms(vtmc_ctx *ctx, float *ms)
+{
+    if (!ctx || !ms) return VTMC_ERR_INVALID_ARG;
+    if (!ctx->fill_timed) return fail(ctx, VTMC_ERR_NO_RESULT, "last_fill_ms before any density fill");
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    VTMC_HIP(ctx, hipEventSynchronize(ctx->ev_fill[1]));
+    VTMC_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_fill[0], ctx->ev_fill[1]));
     return VTMC_OK;
 }
 

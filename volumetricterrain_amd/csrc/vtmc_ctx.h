@@ -1,0 +1,86 @@
+// vtmc_ctx.h -- the context object behind include/vtmc.h and the small host helpers every
+// translation unit of the C-ABI layer shares (vtmc_api.hip, chunk_io.hip, comm.hip).  Not installed.
+#ifndef VTMC_CTX_H
+#define VTMC_CTX_H
+#include "../../include/vtmc.h"
+#include "vtmc_internal.h"
+
+#include <string>
+#include <vector>
+
+struct VtmcDevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+// An extract that has been queued on a stream and not yet completed by extract_finish().
+struct VtmcPending {
+    bool active = false;    // queued, extract_finish() not yet called
+    bool launched = false;  // false: the empty-batch early exit (nothing to wait for but the memsets)
+    vtmc::BlockSpace sp{};
+    int n_volumes = 0;
+    bool indexed = false;
+    hipStream_t stream = nullptr;
+    size_t tcap = 0, vcap = 0;  // capacities the last emit launch was given
+};
+
+struct vtmc_ctx {
+    int device = 0;
+    int n_cus = 256;
+    hipStream_t stream = nullptr;
+    vtmc::DeviceTables tables{nullptr, nullptr};
+    VtmcDevBuf d_vert, d_trinum;
+    VtmcDevBuf counts, offsets, active, partials, totals, volcounts, cases, tris, input, list, perm, origins;
+    VtmcDevBuf vcounts, voffsets, vpartials, vtotals, verts, indices;  // indexed output
+    int output_mode = VTMC_OUTPUT_SOUP;
+    bool last_indexed = false;
+    int64_t last_verts = 0;
+    uint32_t *h_totals = nullptr;  // pinned: the scan's totals ({T sat, nActive, T lo, T hi}, then the vertex scan's), 64 words
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0..3] stage timing, [4] staging copies
+    float stage_ms[4] = {0, 0, 0, 0};
+    hipEvent_t ev_fill[2] = {nullptr, nullptr};  // around the last density kernel (vtmc_last_fill_ms)
+    bool fill_timed = false;
+    VtmcPending pending;
+    // last result
+    bool has_result = false;
+    vtmc::BlockSpace last_space{};
+    int last_blocks = 0;
+    int last_volumes = 0;
+    int64_t last_tris = 0;
+    vtmc::Tuning tune;
+    // device-resident terrain (vtmc_terrain_*)
+    VtmcDevBuf terrain, heightmap;
+    vtmc::TerrainShape tshape{};
+    bool has_terrain = false;
+    uint32_t terrain_events = 0;
+    std::vector<int32_t> dirty;  // (bx,by,bz) of the last vtmc_terrain_update, ordered by block id
+    bool dirty_is_all = false;   // ... or every block (the list is then materialised on demand only)
+    uint64_t perm_seed = 0;
+    bool perm_valid = false;
+    // chunk_io.hip: file image being assembled / last image read
+    VtmcDevBuf chunk_image;
+    // comm.hip: RCCL communicator (opaque ncclComm_t) + the padded send buffer of the counts all-gather
+    void *comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    VtmcDevBuf comm_send;
+    std::string err;
+};
+
+namespace vtmc {
+// sets the context's (or, with ctx == nullptr, the thread's create-) error text and returns `code`
+int fail(vtmc_ctx *ctx, int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
+int ensure(vtmc_ctx *ctx, VtmcDevBuf &b, size_t bytes);  // grow-only device buffer
+void release(VtmcDevBuf &b);
+const char *create_error_text();
+void comm_release(vtmc_ctx *ctx);  // comm.hip: called by vtmc_destroy
+}  // namespace vtmc
+
+#define VTMC_HIP(ctx, expr)                                                                                \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return vtmc::fail(ctx, VTMC_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                              __FILE__, __LINE__);                                                         \
+    } while (0)
+
+#endif

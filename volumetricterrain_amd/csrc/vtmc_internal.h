@@ -60,18 +60,7 @@ struct Tuning {
     int classify_ablate = 0;  // diagnostics only: 1 no halo rows (output invalid)
     int emit_row_masks = 1;   // emit loads only the tile rows next to cells with triangles (masks from classify)
     int emit_group_log2 = 0;  // each wave takes 2^g consecutive active-list entries per round
-    int sweep = 0;            // 1: dense x-fastest volumes take the single-pass kernel (sweep_kernels.hip, slower so far: DESIGN.md); 0: classify -> scan -> emit
-    int sweep_wgs_per_cu = 3;
 };
-
-// sweep scratch: kCtrlWords control words (zeroed with the status words before every launch), then
-// one 8-byte status word per brick
-constexpr int kCtrlError = 0;      // != 0: a bounded spin gave up
-constexpr int kCtrlTotalLo = 64;   // T, written by the wave that owns the last brick
-constexpr int kCtrlTotalHi = 65;
-constexpr int kTicketGroups = 8;   // ticket counters, one per 256-byte line
-constexpr int kCtrlTicket = 128;
-constexpr int kCtrlWords = kCtrlTicket + 64 * kTicketGroups;
 
 // scan scratch layout
 constexpr int kQueueWords = 8 * 16 * 64;  // up to 16 ticket counters per XCD, 256 bytes apart
@@ -84,8 +73,9 @@ hipError_t launch_classify_blocks(const BlockSpace &sp, const DeviceTables &tb, 
 hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
                                  uint32_t *vcounts_or_null, int ablate, hipStream_t stream);
 hipError_t launch_scan(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list,
-                       uint32_t *partials, uint32_t *totals, int bpv, int n_volumes,
-                       uint32_t *volume_counts, hipStream_t stream);
+                       uint32_t *partials, uint32_t *totals, hipStream_t stream);
+hipError_t launch_volume_counts(const uint32_t *offsets, const uint32_t *voffsets_or_null, int bpv, int n_volumes,
+                                uint32_t *volume_counts, hipStream_t stream);
 hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets,
                        const int32_t *active_list, const uint32_t *totals, const uint32_t *counts_or_null, uint32_t capacity,
                        void *triangles, int n_cus, const Tuning &tune, unsigned *queue, hipStream_t stream);
@@ -94,14 +84,6 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
                                const int32_t *active_list, const uint32_t *totals, const uint32_t *vtotals, uint32_t tri_capacity,
                                uint32_t vert_capacity, void *vertices, void *indices, int n_cus, const Tuning &tune, unsigned *queue,
                                hipStream_t stream);
-
-// sweep_kernels.hip: single-pass classify + chained scan + emit for dense volumes with stride_x == 1.
-// `scratch` holds sweep_scratch_bytes(sp) bytes; offsets gets n_blocks + 1 entries; T lands in
-// scratch[kCtrlTotalLo/Hi], a non-zero scratch[kCtrlError] means the launch failed.
-size_t sweep_scratch_bytes(const BlockSpace &sp);
-hipError_t launch_sweep(const BlockSpace &sp, const DeviceTables &tb, void *scratch, uint32_t *offsets,
-                        unsigned long long capacity, void *triangles, int n_cus, int n_volumes,
-                        uint32_t *volume_counts, const Tuning &tune, hipStream_t stream);
 
 // terrain.hip: device-resident density grid with the reference's CSG write semantics.
 struct TerrainShape {

@@ -10,7 +10,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import TRI_DTYPE, VERTEX_DTYPE, DensityParams, Modifier, VolumeBatch, VtmcError
+from ._lib import COMM_ID_BYTES, TRI_DTYPE, VERTEX_DTYPE, ChunkView, DensityParams, Modifier, VolumeBatch, VtmcError
 
 
 def _ptr(a):
@@ -148,6 +148,16 @@ class Extractor:
         self._check(self._L.vtmc_extract_volumes_device(self._h, ctypes.byref(vb), stream, flags, ctypes.byref(t)))
         return t.value
 
+    def extract_volumes_device_async(self, d_ptr, n, strides, n_volumes=1, volume_stride=0, stream=None, flags=0):
+        """Queues the extract on `stream` and returns at once; extract_finish() completes it."""
+        vb = VolumeBatch(d_ptr, n[0], n[1], n[2], strides[0], strides[1], strides[2], n_volumes, volume_stride)
+        self._check(self._L.vtmc_extract_volumes_device_async(self._h, ctypes.byref(vb), stream, flags))
+
+    def extract_finish(self):
+        t = ctypes.c_int64()
+        self._check(self._L.vtmc_extract_finish(self._h, ctypes.byref(t)))
+        return t.value
+
     def device_results(self):
         """(triangles, block_tri_offsets, volume_counts) device addresses of the last extract."""
         a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
@@ -159,6 +169,47 @@ class Extractor:
         (async on `stream`): what the multi-GPU driver all-gathers."""
         self._check(self._L.vtmc_copy_volume_counts_device(self._h, d_dst, capacity_volumes, stream))
 
+    def copy_to_host(self, d_ptr, nbytes, stream=None):
+        """Blocking device -> host copy through the library's own HIP runtime (vtmc_copy_to_host)."""
+        out = np.empty(int(nbytes), np.uint8)
+        self._check(self._L.vtmc_copy_to_host(self._h, d_ptr, _ptr(out), int(nbytes), stream))
+        return out
+
+    def copy_u32(self, d_ptr, count, stream=None):
+        return self.copy_to_host(d_ptr, 4 * int(count), stream).view(np.uint32)
+
+    # -- multi-GPU: the RCCL all-gather of per-chunk counts behind the C ABI ---------------------
+    def comm_unique_id(self):
+        """128 opaque bytes drawn by rank 0 (ncclGetUniqueId); the caller distributes them."""
+        buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
+        rc = self._L.vtmc_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p))
+        if rc != 0:
+            raise VtmcError(rc, self._L.vtmc_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_init_rank(self, unique_id, rank, world_size):
+        buf = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._check(self._L.vtmc_comm_init_rank(self._h, ctypes.cast(buf, ctypes.c_void_p), rank, world_size))
+
+    def comm_destroy(self):
+        self._check(self._L.vtmc_comm_destroy(self._h))
+
+    def allgather_volume_counts(self, d_all_counts, volumes_per_rank, stream=None):
+        """Queues the all-gather of the last extract's per-volume {vertices, triangles} on `stream`:
+        d_all_counts (device, world x volumes_per_rank x 2 u32).  Asynchronous."""
+        self._check(self._L.vtmc_allgather_volume_counts(self._h, d_all_counts, volumes_per_rank, stream))
+
+    # -- persisted chunks (device-side packer / loader) -------------------------------------------
+    def chunk_write(self, path, volume, origin, with_samples=True):
+        o = (ctypes.c_int32 * 3)(*[int(v) for v in origin])
+        self._check(self._L.vtmc_chunk_write(self._h, str(path).encode(), volume, ctypes.byref(o), 1 if with_samples else 0))
+
+    def chunk_read(self, path):
+        """Uploads a chunk file; returns the ChunkView of device pointers (valid until the next chunk_* call)."""
+        v = ChunkView()
+        self._check(self._L.vtmc_chunk_read(self._h, str(path).encode(), ctypes.byref(v)))
+        return v
+
     def reserve_triangles(self, capacity):
         self._check(self._L.vtmc_reserve_triangles(self._h, int(capacity)))
 
@@ -166,6 +217,11 @@ class Extractor:
         ms = (ctypes.c_float * 4)()
         self._check(self._L.vtmc_last_stage_ms(self._h, ctypes.byref(ms)))
         return {"classify": ms[0], "scan": ms[1], "emit": ms[2], "total": ms[3]}
+
+    def last_fill_ms(self):
+        ms = ctypes.c_float()
+        self._check(self._L.vtmc_last_fill_ms(self._h, ctypes.byref(ms)))
+        return ms.value
 
     def set_tuning(self, **kv):
         for k, v in kv.items():

@@ -6,8 +6,6 @@ its own 10^3 samples, VoxelTerrain.cs:346-359).  Chunk c belongs to rank c % wor
 exchange is one all-gather of the per-chunk {vertex count, triangle count} pairs, after which every
 rank derives the global offsets with a local exclusive scan.  No density or mesh data crosses GPUs.
 """
-import ctypes
-
 import numpy as np
 
 
@@ -63,29 +61,3 @@ def allgather_counts(local_counts, group=None):
     out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
     dist.all_gather_into_tensor(out, flat, group=group)   # one collective; flat views suit nccl and gloo alike
     return out.view((world,) + tuple(local_counts.shape))
-
-
-# -- tiny device -> host copies through the HIP runtime (no torch tensor owns library buffers) ----
-_hip = None
-
-
-def _hiprt():
-    global _hip
-    if _hip is None:
-        _hip = ctypes.CDLL("libamdhip64.so")
-        _hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-        _hip.hipMemcpy.restype = ctypes.c_int
-    return _hip
-
-
-def copy_device_bytes(d_ptr, nbytes):
-    out = np.empty(nbytes, np.uint8)
-    if nbytes:
-        rc = _hiprt().hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_ptr), nbytes, 2)
-        if rc != 0:
-            raise RuntimeError("hipMemcpy D2H failed with %d" % rc)
-    return out
-
-
-def copy_device_u32(d_ptr, count):
-    return copy_device_bytes(d_ptr, 4 * count).view(np.uint32)

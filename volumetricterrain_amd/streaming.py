@@ -73,6 +73,6 @@ class ChunkStream:
         counts, total = [], 0
         for _, org, T, ex in self.batches():
             _, _, vc_ptr = ex.device_results()
-            counts.append(sharding.copy_device_u32(vc_ptr, 2 * len(org)).reshape(-1, 2).astype(np.int64))
+            counts.append(ex.copy_u32(vc_ptr, 2 * len(org)).reshape(-1, 2).astype(np.int64))
             total += T
         return total, (np.concatenate(counts) if counts else np.zeros((0, 2), np.int64))
