@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the marching-cubes extraction path on MI355X.
 
-Workload (BASELINE.json configs[2], the one `metric` is quoted on): a 1024^3-cell perlin3d grid
-held as 8^3 chunks of 128^3 cells (130^3 samples each, 4.50 GB), resident in HBM.  One "step" =
-one pass of the hot path over that batch: classify+count -> prefix scan / compaction -> fused
-normals + triangle emit (--sweep: the experimental single-pass kernel), ending when the host knows T (and, for N > 1, after the RCCL all-gather
-of the per-chunk {vertex, triangle} counts).  Weak scaling: every rank owns 512 chunks of a
-1024 x 1024 x (1024*N) world, chunk c -> rank c % N.
+--config grid1024 (default; BASELINE.json configs[2] at N = 1, configs[3] at N > 1 -- the one `metric`
+is quoted on): a 1024^3-cell perlin3d grid held as 8^3 chunks of 128^3 cells (130^3 samples each,
+4.50 GB), resident in HBM.  One "step" = one pass of the hot path over the rank's chunks: classify +
+count -> prefix scan / compaction -> fused normals + triangle emit, ending when the host knows T and
+(N > 1) every chunk's global offsets.  N > 1 is STRONG scaling by default, as configs[3] states it:
+the world stays 1024^3, chunk c belongs to rank c % N (64 chunks each at N = 8), and the step ends
+with the path's one collective, the RCCL all-gather of per-chunk {vertices, triangles} over xGMI
+(vtmc_allgather_volume_counts, queued on the extract's stream; --scaling weak keeps 512 chunks per
+rank on a 1024 x 1024 x 1024*N world instead).
+
+--config stream2048 (BASELINE.json configs[4]): a 2048^3-cell fbm8 world (36 GB of samples) streamed
+as double-buffered batches of 128^3 chunks: batch k+1 is sampled while batch k is extracted; one
+step = one pass over the rank's 4096 / N chunks, sampling included.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -16,77 +23,60 @@ Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (do
 algorithmic bytes / HIP-event time on the kernels' own stream) and `cpu_baseline` (the CPU oracle
 timed on this box's host cores on a bounded sample of the same device-generated field).
 """
-import argparse
-import json
 import os
-import sys
-import time
 
-import numpy as np
+# the CPU leg pins its OpenMP threads; libgomp reads these when it is first mapped (import torch)
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
+
+import argparse  # noqa: E402
+import json  # noqa: E402
+import statistics  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+VALU_PEAK_LANE_OPS = 78.6e12  # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (157.3 TFLOP/s FP32 vector = 2 flops per fma)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--grid", "--n", dest="n", type=int, default=1024, help="cells per axis of one rank's grid")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="grid1024", choices=["grid1024", "stream2048"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: the same 1024^3 world sharded (BASELINE configs[3]) or 512 chunks per rank")
+    ap.add_argument("--grid", "--n", dest="n", type=int, default=None, help="cells per axis (reduced sizes for tests)")
     ap.add_argument("--chunk", type=int, default=128, help="cells per axis of a chunk")
-    ap.add_argument("--kind", default="perlin3d", choices=["perlin3d", "fbm8"])
+    ap.add_argument("--batch", type=int, default=64, help="stream2048: chunks per double-buffered batch")
+    ap.add_argument("--kind", default=None, choices=["perlin3d", "fbm8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-chunks", type=int, default=8, help="chunks the CPU oracle is timed on")
+    ap.add_argument("--cpu-sample-chunks", type=int, default=32, help="chunks the CPU oracle is timed on")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0: physical cores in this process's CPU share, at most 16 per GPU)")
     ap.add_argument("--no-dense", action="store_true", help="A/B: force the per-block classify kernel")
-    ap.add_argument("--sweep", action="store_true", help="A/B: the experimental single-pass kernel instead of classify -> scan -> emit")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config == "stream2048":
+        args.n = args.n or 2048
+        args.kind = args.kind or "fbm8"
+        args.steps = 3 if args.steps is None else args.steps
+        args.warmup = 1 if args.warmup is None else args.warmup
+    else:
+        args.n = args.n or 1024
+        args.kind = args.kind or "perlin3d"
+        args.steps = 20 if args.steps is None else args.steps
+        args.warmup = 3 if args.warmup is None else args.warmup
+    return args
 
 
-def cpu_baseline(d_field, dim, chunk, n_sample, kind_label):
-    """Time the CPU oracle (oracle/mc_oracle.c, the restatement of the reference kernels: 'port')
-    on the first n_sample chunks of the SAME device-generated field, all host cores + 1 core."""
-    import ctypes
-    import oracle
-    L = oracle.lib()
-    threads = oracle.max_threads()
-    blocks = oracle.all_blocks(chunk, chunk, chunk)
-    vols = [d_field[v * dim ** 3:(v + 1) * dim ** 3].cpu().numpy() for v in range(n_sample)]
-    sx, sy, sz = 1, dim, dim * dim
-    offs = np.empty(len(blocks) + 1, np.int32)
-    # size the output once (count pass), reuse the buffer so page faults are not timed
-    totals = [L.vto_extract_grid(oracle._p(v), sx, sy, sz, oracle._p(blocks), len(blocks), None, 0,
-                                 oracle._p(offs), None, threads) for v in vols]
-    buf = np.zeros(max(max(totals), 1), oracle.TRI_DTYPE)
-
-    def run(nthreads, vs):
-        t0 = time.perf_counter()
-        tris = 0
-        for v in vs:
-            tris += L.vto_extract_grid(oracle._p(v), sx, sy, sz, oracle._p(blocks), len(blocks), oracle._p(buf),
-                                       len(buf), oracle._p(offs), None, nthreads)
-        return time.perf_counter() - t0, tris
-
-    best_all = min(run(threads, vols)[0] for _ in range(3))
-    t_one, _ = run(1, vols[:1])
-    cells = chunk ** 3
-    return {
-        "value": round(n_sample * cells / best_all / 1e6, 2),
-        "unit": "Mvoxels/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": "%d chunks of %d^3 cells (%s, same device-generated field), OpenMP over blocks, best of 3"
-                  % (n_sample, chunk, kind_label),
-        "mtris_per_s": round(sum(totals) / best_all / 1e6, 2),
-        "single_core_mvoxels_per_s": round(cells / t_one / 1e6, 2),
-        "cpu_model": _cpu_model(),
-        "host_cores": os.cpu_count(),
-    }
-
-
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (oracle/mc_oracle.c, "port") on this box's host cores
+# ------------------------------------------------------------------------------------------------
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -97,13 +87,105 @@ def _cpu_model():
     return "unknown"
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
-    import volumetricterrain_amd as vt
-    from volumetricterrain_amd import sharding
+def cpu_share():
+    """Physical cores this process may use: /proc/cpuinfo (physical id, core id) pairs of the CPUs in
+    sched_getaffinity, capped by the cgroup's cpu.max quota when one is set."""
+    aff = sorted(os.sched_getaffinity(0))
+    cores, cur = {}, {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if "processor" in cur:
+                    cores[int(cur["processor"])] = (cur.get("physical id", "0"), cur.get("core id", cur["processor"]))
+                cur = {}
+                continue
+            k, v = line.split(":", 1)
+            cur[k.strip()] = v.strip()
+        if "processor" in cur:
+            cores[int(cur["processor"])] = (cur.get("physical id", "0"), cur.get("core id", cur["processor"]))
+    except OSError:
+        pass
+    physical = len({cores.get(c, ("0", str(c))) for c in aff})
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(period)))
+    except (OSError, ValueError):
+        pass
+    return {"affinity_cpus": len(aff), "physical_cores": physical, "cgroup_quota_cores": quota}
 
+
+def cpu_baseline(volumes, dim, chunk, kind_label, want_threads, n_gpus_on_box):
+    """volumes: list of host float32 arrays (one 130^3 chunk each) of the SAME device-generated field.
+    All-cores leg: >= 5 repetitions of >= 0.5 s each (the sample is looped inside a repetition until
+    0.5 s have passed), every repetition's rate reported with min / median; then a one-thread leg."""
+    import oracle
+    L = oracle.lib()
+    share = cpu_share()
+    cap = 16 * max(1, n_gpus_on_box)   # the pool's CPU share per GPU; more threads than that measure the neighbours
+    threads = want_threads or min(x for x in (share["physical_cores"], share["cgroup_quota_cores"] or 1 << 30, cap, oracle.max_threads()))
+    blocks = oracle.all_blocks(chunk, chunk, chunk)
+    sx, sy, sz = 1, dim, dim * dim
+    offs = np.empty(len(blocks) + 1, np.int32)
+    # count pass first: sizes the output once and touches every input page before anything is timed
+    totals = [L.vto_extract_grid(oracle._p(v), sx, sy, sz, oracle._p(blocks), len(blocks), None, 0,
+                                 oracle._p(offs), None, threads) for v in volumes]
+    buf = np.zeros(max(max(totals), 1), oracle.TRI_DTYPE)
+    cells = chunk ** 3
+
+    def repetition(nthreads, vs, min_s=0.5):
+        t0 = time.perf_counter()
+        done = 0
+        while True:
+            for v in vs:
+                L.vto_extract_grid(oracle._p(v), sx, sy, sz, oracle._p(blocks), len(blocks), oracle._p(buf),
+                                   len(buf), oracle._p(offs), None, nthreads)
+                done += 1
+            dt = time.perf_counter() - t0
+            if dt >= min_s:
+                return done * cells / dt / 1e6, dt
+
+    repetition(threads, volumes, 0.0)   # warm-up: thread team, output pages
+    all_runs = [repetition(threads, volumes) for _ in range(5)]
+    one_runs = [repetition(1, volumes[:1]) for _ in range(3)]
+    rates = [r for r, _ in all_runs]
+    return {
+        "value": round(statistics.median(rates), 2),
+        "unit": "Mvoxels/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d chunks of %d^3 cells (%s, same device-generated field), OpenMP over blocks pinned close/cores, "
+                  "5 repetitions of >= 0.5 s, median" % (len(volumes), chunk, kind_label),
+        "repetitions_mvoxels_per_s": [round(r, 2) for r in rates],
+        "repetition_seconds": [round(s, 3) for _, s in all_runs],
+        "min_mvoxels_per_s": round(min(rates), 2),
+        "max_mvoxels_per_s": round(max(rates), 2),
+        "mtris_per_s": round(statistics.median(rates) * sum(totals) / (len(volumes) * cells), 2),
+        "single_core_mvoxels_per_s": round(statistics.median(r for r, _ in one_runs), 2),
+        "single_core_repetitions": [round(r, 2) for r, _ in one_runs],
+        "cpu_model": _cpu_model(),
+        "host_cpus": os.cpu_count(),
+        "cpu_share": share,
+        "omp": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")},
+    }
+
+
+# ------------------------------------------------------------------------------------------------
+def pmc_traffic(dom, matches):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes -- a constant taken
+    on the builder's lease of the same workload, NOT measured in this run (traffic_source says so)."""
+    f = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not matches or not os.path.exists(f):
+        return None, None
+    try:
+        j = json.load(open(f))
+        return j.get(dom + "_hbm_bytes"), "committed constant: " + j.get("source", "profiles/pmc_traffic.json")
+    except Exception:
+        return None, None
+
+
+def init_distributed(args, torch, dist):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -122,75 +204,119 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+    return rank, world, local, backend
 
+
+def native_comm(ex, rank, world, backend, dist):
+    """The library's own RCCL communicator (vtmc_comm_init_rank): rank 0 draws the id, torch.distributed
+    only carries its 128 bytes to the other ranks.  Returns False when the native path is unavailable
+    (VTMC_BENCH_NATIVE_RCCL=0, or two ranks rehearsing on one device), the torch collective is used then."""
+    if world == 1 or os.environ.get("VTMC_BENCH_NATIVE_RCCL", "1") != "1" or backend != "nccl":
+        return False
+    box = [ex.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ex.comm_init_rank(box[0], rank, world)
+    return True
+
+
+def reduce_max_sum(elapsed, tris, world, backend, torch, dist):
+    if world == 1:
+        return elapsed, float(tris)
+    dev = "cuda" if backend == "nccl" else "cpu"
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ts = torch.tensor([float(tris)], dtype=torch.float64, device=dev)
+    dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+    return float(el[0]), float(ts[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# grid1024: resident grid, extraction only (configs[2] / configs[3])
+# ------------------------------------------------------------------------------------------------
+def run_grid(args, torch, dist):
+    import volumetricterrain_amd as vt
+    from volumetricterrain_amd import sharding
+    rank, world, local, backend = init_distributed(args, torch, dist)
     n, c = args.n, args.chunk
     dim = c + 2
-    world_dims = (n, n, n * world)
+    strong = world > 1 and args.scaling == "strong"
+    world_dims = (n, n, n) if (strong or world == 1) else (n, n, n * world)
     origins = sharding.chunk_origins(world_dims, c, rank, world)
     n_chunks = len(origins)
+    n_chunks_total = (world_dims[0] // c) * (world_dims[1] // c) * (world_dims[2] // c)
+    per_rank = (n_chunks_total + world - 1) // world   # slots per rank in the gathered array (zero-padded)
     bpv = (c // 8) ** 3
     ex = vt.Extractor(local)
-    # one explicit (non-default) HIP stream for everything: the library's kernels, the counts copy and
-    # the RCCL all-gather are ordered by it (a NULL handle would mean "the context's own stream" to the
-    # library, which torch's collectives know nothing about)
+    # one explicit (non-default) HIP stream for everything: the library's kernels, the all-gather and the
+    # copy of the gathered counts are ordered by it
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     prm = vt.density_params(args.kind, n)
 
     # -- setup (untimed): density field generated on the device, chunk by chunk with halos -------
-    d_field = torch.empty(n_chunks * dim ** 3, dtype=torch.float32, device="cuda")
+    d_field = torch.empty(max(n_chunks, 1) * dim ** 3, dtype=torch.float32, device="cuda")
     t0 = time.perf_counter()
-    ex.density_fill_device(prm, origins, (dim, dim, dim), (1, dim, dim * dim), dim ** 3, d_field.data_ptr(),
-                           stream.cuda_stream)
+    ex.density_fill_device(prm, origins, (dim, dim, dim), (1, dim, dim * dim), dim ** 3, d_field.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     sampler_s = time.perf_counter() - t0
+    sampler_kernel_ms = ex.last_fill_ms()
 
+    native = native_comm(ex, rank, world, backend, dist)
     flags = 2 if args.no_dense else 0
-    if args.sweep:
-        ex.set_tuning(sweep=1)
-    fused = args.sweep and not args.no_dense
-    counts_dev = torch.zeros((n_chunks, 2), dtype=torch.int32, device="cuda")
+    gathered = torch.zeros((world, per_rank, 2), dtype=torch.int32, device="cuda")
+    gathered_host = torch.zeros((world, per_rank, 2), dtype=torch.int32).pin_memory()
+    counts_dev = torch.zeros((per_rank, 2), dtype=torch.int32, device="cuda")
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     stage_acc = {"classify": 0.0, "scan": 0.0, "emit": 0.0, "total": 0.0}
+    gather_ms = []
 
     def step(accumulate=False):
-        T = ex.extract_volumes_device(d_field.data_ptr(), (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3,
-                                      stream.cuda_stream, flags)
+        """queue: classify -> scan -> emit [-> all-gather -> copy of the gathered counts]; ONE host wait."""
+        ex.extract_volumes_device_async(d_field.data_ptr(), (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, stream.cuda_stream, flags)
+        if world > 1:
+            ev0.record(stream)
+            if native:     # the path's one collective, behind the C ABI, on the same stream
+                ex.allgather_volume_counts(gathered.data_ptr(), per_rank, stream.cuda_stream)
+            else:
+                ex.copy_volume_counts_device(counts_dev.data_ptr(), per_rank, stream.cuda_stream)
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(gathered.view(-1), counts_dev.view(-1))
+                else:   # gloo rehearsal: through the host
+                    stream.synchronize()
+                    g = sharding.allgather_counts(counts_dev.cpu())
+                    gathered.copy_(g.to("cuda"))
+            ev1.record(stream)
+            gathered_host.copy_(gathered, non_blocking=True)
+        T = ex.extract_finish()   # the one stream wait of the step: T, and everything queued behind the extract
+        offs = None
+        if world > 1:
+            # rank r holds chunks r, r + N, ...: chunk order = slot-major; every rank's local exclusive scan
+            offs = sharding.global_offsets(gathered_host.numpy().transpose(1, 0, 2).reshape(-1, 2)[:n_chunks_total])
         if accumulate:
             for k, v in ex.last_stage_ms().items():
                 stage_acc[k] += v
-        if world > 1:
-            # the only exchange of the path: all-gather of per-chunk {vertices, triangles}
-            ex.copy_volume_counts_device(counts_dev.data_ptr(), n_chunks, stream.cuda_stream)
-            gathered = sharding.allgather_counts(counts_dev if backend == "nccl" else counts_dev.cpu())
-            offs = torch.cumsum(gathered.transpose(0, 1).reshape(-1, 2).to(torch.int64), 0)  # global chunk order
-            return T, offs
-        return T, None
+            if world > 1:
+                gather_ms.append(ev0.elapsed_time(ev1))
+        return T, offs
 
     for _ in range(args.warmup):
-        T, _ = step()
+        T, offs = step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        T, _ = step(accumulate=True)
+        T, offs = step(accumulate=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    elapsed, total_tris = reduce_max_sum(elapsed, T, world, backend, torch, dist)
     if world > 1:
-        red_dev = "cuda" if backend == "nccl" else "cpu"
-        el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el[0])
-        tsum = torch.tensor([float(T)], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        total_tris = float(tsum[0])
-    else:
-        total_tris = float(T)
+        assert int(offs[-1, 1]) == int(total_tris), "gathered chunk counts do not add up to the ranks' triangle totals"
 
     ms_per_step = elapsed / args.steps * 1e3
-    cells_total = float(n) ** 3 * world
+    cells_total = float(world_dims[0]) * world_dims[1] * world_dims[2]
     value = cells_total / (elapsed / args.steps) / 1e6
 
     if rank == 0:
@@ -198,8 +324,8 @@ def main():
         avg = {k: v / args.steps for k, v in stage_acc.items()}
         samples = n_chunks * dim ** 3
         _, off_ptr, _ = ex.device_results()
-        offs = sharding.copy_device_u32(off_ptr, n_chunks * bpv + 1).astype(np.int64)
-        n_active = int((np.diff(offs) > 0).sum())
+        boffs = ex.copy_u32(off_ptr, n_chunks * bpv + 1).astype(np.int64)
+        n_active = int((np.diff(boffs) > 0).sum())
         alg = {
             # DESIGN.md "algorithmic bytes": classify reads every sample once and writes one count per block
             "classify": 4.0 * samples + 4.0 * n_chunks * bpv,
@@ -207,24 +333,14 @@ def main():
             "emit": 76.0 * T + 4000.0 * n_active,
             "scan": 4.0 * n_chunks * bpv * 3,
         }
-        if fused:
-            # single-pass kernel: every sample read once, one offset per block and every triangle written once
-            alg["sweep"] = 4.0 * samples + 4.0 * n_chunks * bpv + 76.0 * T
-            avg["sweep"] = avg["classify"]
-        dom = "sweep" if fused else max(("classify", "emit"), key=lambda k: avg[k])
+        dom = max(("classify", "emit"), key=lambda k: avg[k])
         ach = alg[dom] / (avg[dom] * 1e-3) / 1e9
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_file) and n == 1024 and c == 128 and args.kind == "perlin3d":  # the PMC passes were taken on this workload
-            try:
-                traffic = json.load(open(pmc_file)).get(dom + "_kernel_hbm_bytes")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = pmc_traffic(dom + "_kernel", world == 1 and n == 1024 and c == 128 and args.kind == "perlin3d" and not args.no_dense)
         roofline = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes": alg[dom], "avg_ms": round(avg[dom], 4)}
         per_kernel = {k: {"avg_ms": round(avg[k], 4), "alg_GBps": round(alg[k] / (avg[k] * 1e-3) / 1e9, 1) if avg[k] > 0 else None}
-                      for k in (("sweep",) if fused else ("classify", "scan", "emit"))}
+                      for k in ("classify", "scan", "emit")}
         # SURVEY.md 8d whole-path figure on one rank: 4*S + 76*T + 8*C over the device time of the three stages
         path_bytes = 4.0 * samples + 76.0 * T + 8.0 * n_chunks
         path = {"bytes": path_bytes, "device_ms": round(avg["total"], 4),
@@ -233,9 +349,18 @@ def main():
                 "read_only_frac_of_peak": round(4.0 * samples / (avg["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         cpu = None
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
-            cpu = cpu_baseline(d_field, dim, c, min(args.cpu_sample_chunks, n_chunks), args.kind)
+            k = min(args.cpu_sample_chunks, n_chunks)
+            vols = [d_field[v * dim ** 3:(v + 1) * dim ** 3].cpu().numpy() for v in range(k)]
+            cpu = cpu_baseline(vols, dim, c, args.kind, args.cpu_threads, torch.cuda.device_count())
+        if world == 1:
+            wl = "%s %d^3 cells as %d chunks of %d^3 (%d^3 samples incl. halo), resident in HBM" % (args.kind, n, n_chunks, c, dim)
+        elif strong:
+            wl = ("%s %d^3 cells as %d chunks of %d^3, chunk c -> rank c %% %d (%d per rank), all-gather of per-chunk counts"
+                  % (args.kind, n, n_chunks_total, c, world, n_chunks))
+        else:
+            wl = "%s %d^3 cells per GPU as %d chunks of %d^3, chunk c -> rank c %% N (weak scaling world 1024 x 1024 x 1024N)" % (args.kind, n, n_chunks, c)
         out = {
-            "metric": "marching-cubes extraction throughput on a %d^3 %s grid per GPU (Mvoxels/s)" % (n, args.kind),
+            "metric": "marching-cubes extraction throughput on a %d^3 %s grid (Mvoxels/s)" % (n, args.kind),
             "value": round(value, 1),
             "unit": "Mvoxels/s",
             "n_gpus": world,
@@ -243,27 +368,136 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (strong or world == 1) else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s %d^3 cells per GPU as %d chunks of %d^3 (130^3 samples incl. halo), chunk c -> rank c %% N"
-                                   % (args.kind, n, n_chunks, c),
-                       "grid": n, "chunk": c, "chunks_per_gpu": n_chunks, "kind": args.kind, "seed": 1337,
-                       "pipeline": "single-pass sweep kernel" if fused else ("classify(per-block) -> scan -> emit" if args.no_dense else "classify(dense) -> scan -> emit")},
+            "config": {"workload": wl, "grid": n, "chunk": c, "chunks_per_gpu": n_chunks, "kind": args.kind, "seed": 1337,
+                       "pipeline": "classify(per-block) -> scan -> emit" if args.no_dense else "classify(dense) -> scan -> emit",
+                       "collective": None if world == 1 else ("rccl all-gather via libvtmc (vtmc_allgather_volume_counts)" if native
+                                                              else "torch.distributed all_gather (%s)" % backend)},
             "mtris_per_s": round(total_tris / (elapsed / args.steps) / 1e6, 1),
-            "triangles_per_gpu": int(T),
-            "active_blocks_per_gpu": n_active,
+            "triangles_rank0": int(T),
+            "triangles_total": int(total_tris),
+            "active_blocks_rank0": n_active,
             "roofline": roofline,
             "kernels": per_kernel,
             "path_roofline": path,
+            "allgather_ms": None if world == 1 else {"avg": round(statistics.mean(gather_ms), 4), "max": round(max(gather_ms), 4),
+                                                     "note": "HIP events around the collective on the extract's stream, rank 0"},
+            "host_ms_per_step_beyond_kernels": round(ms_per_step - avg["total"], 4),
             "cpu_baseline": cpu,
             "sampler_s": round(sampler_s, 4),
+            "sampler_kernel_ms": round(sampler_kernel_ms, 3),
         }
         print(json.dumps(out))
     ex.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# stream2048: sampler + extractor, double-buffered batches (configs[4])
+# ------------------------------------------------------------------------------------------------
+def run_stream(args, torch, dist):
+    from volumetricterrain_amd.streaming import ChunkStream
+    rank, world, local, backend = init_distributed(args, torch, dist)
+    n, c = args.n, args.chunk
+    dim = c + 2
+    with ChunkStream(n, c, args.batch, args.kind, n, rank=rank, world_size=world, device=local) as st:
+        n_chunks = len(st.origins)
+        cells_total = float(n) ** 3
+        for _ in range(max(args.warmup, 1)):   # buffers grow to their steady size
+            st.run()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            total, counts = st.run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        elapsed, total_tris = reduce_max_sum(elapsed, total, world, backend, torch, dist)
+        if world > 1:   # the same single exchange as config 4: per-chunk counts of every rank
+            from volumetricterrain_amd import sharding
+            per_rank = ((n // c) ** 3 + world - 1) // world
+            loc = torch.zeros((per_rank, 2), dtype=torch.int32)
+            loc[:n_chunks] = torch.from_numpy(counts.astype(np.int32))
+            g = sharding.allgather_counts(loc.cuda() if backend == "nccl" else loc)
+            assert int(g[..., 1].sum()) == int(total_tris)
+        # diagnostic pass, serialised (fill waits, then extract): per-kernel device times by HIP events
+        fill_ms, stage = [], {"classify": 0.0, "scan": 0.0, "emit": 0.0, "total": 0.0}
+        t0 = time.perf_counter()
+        for k in range(st.n_batches()):
+            org = st._origins_of(k)
+            st._ex[0].density_fill_device(st.params, org, (dim, dim, dim), (1, dim, dim * dim), dim ** 3, st._buf[0].data_ptr())
+            fill_ms.append(st._ex[0].last_fill_ms())
+            st._ex[0].extract_volumes_device(st._buf[0].data_ptr(), (c, c, c), (1, dim, dim * dim), len(org), dim ** 3)
+            for kk, v in st._ex[0].last_stage_ms().items():
+                stage[kk] += v
+        serial_s = time.perf_counter() - t0
+    if rank == 0:
+        step_s = elapsed / args.steps
+        samples = n_chunks * dim ** 3
+        nb = len(fill_ms)
+        kern = {"density_column_kernel": sum(fill_ms), "classify_dense_kernel": stage["classify"], "scan": stage["scan"], "emit_kernel": stage["emit"]}
+        dom = max(kern, key=kern.get)
+        octaves = st.params.octaves
+        if dom == "density_column_kernel":
+            alg_bytes = 4.0 * samples / nb          # per launch: every sample written once
+        elif dom == "classify_dense_kernel":
+            alg_bytes = (4.0 * samples + 4.0 * n_chunks * st.bpv) / nb
+        else:
+            alg_bytes = 76.0 * total / nb           # + 4000 B per non-empty block, not counted here
+        avg_ms = kern[dom] / nb
+        ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # the sampler's own bound is the vector ALU: ~5 lane-ops per sample-octave in a cell, ~45 per face rebuild
+        # (4 / 2048 * 2^o rebuilds per sample at octave o) -- DESIGN.md; reported next to the HBM figure
+        lane_ops = samples * sum(5.0 + 45.0 * min(1.0, st.params.frequency * (st.params.lacunarity ** o)) for o in range(octaves)) + 6.0 * samples
+        out = {
+            "metric": "streamed sampler + marching-cubes extraction throughput on a %d^3 %s world (Mvoxels/s)" % (n, args.kind),
+            "value": round(cells_total / step_s / 1e6, 1),
+            "unit": "Mvoxels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": max(args.warmup, 1),
+            "ms_per_step": round(step_s * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s %d^3 cells streamed as %d chunks of %d^3 per rank (chunk c -> rank c %% %d), double-buffered batches of %d chunks, "
+                                   "sampling + per-vertex normals + extraction" % (args.kind, n, n_chunks, c, world, st.batch),
+                       "grid": n, "chunk": c, "chunks_per_gpu": n_chunks, "kind": args.kind, "seed": 1337, "batch_chunks": st.batch},
+            "mtris_per_s": round(total_tris / step_s / 1e6, 1),
+            "triangles_total": int(total_tris),
+            "samples_GB_rank0": round(samples * 4 / 1e9, 2),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
+                         "algorithmic_bytes": alg_bytes, "avg_ms": round(avg_ms, 4), "launches_per_step": nb},
+            "sampler_valu": {"lane_ops_per_step": lane_ops, "achieved_lane_ops_per_s": round(lane_ops / (sum(fill_ms) * 1e-3), 1),
+                             "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "frac": round(lane_ops / (sum(fill_ms) * 1e-3) / VALU_PEAK_LANE_OPS, 4)},
+            "kernels_ms_per_step_serialised": {k: round(v, 3) for k, v in kern.items()},
+            "serialised_step_ms": round(serial_s * 1e3, 3),
+            "overlap_gain": round(serial_s / step_s, 3),
+            "cpu_baseline": None,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    if args.config == "stream2048":
+        run_stream(args, torch, dist)
+    else:
+        run_grid(args, torch, dist)
 
 
 if __name__ == "__main__":

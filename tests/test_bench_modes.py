@@ -1,0 +1,59 @@
+"""bench.py's modes at reduced size on the GPU box: the N = 1 line (roofline + reproducible
+cpu_baseline), BASELINE configs[3] as STRONG scaling (two ranks rehearsed on one device over gloo:
+RCCL refuses two ranks per device, the driver's runs use one GPU per rank and the library's own RCCL
+all-gather) and configs[4] as the streamed sampler + extractor."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_carries_roofline_and_reproducible_cpu_leg():
+    j = run([sys.executable, "bench.py", "--grid", "256", "--steps", "3", "--warmup", "1", "--cpu-sample-chunks", "2"])
+    assert j["n_gpus"] == 1 and j["unit"] == "Mvoxels/s" and j["value"] > 0 and j["scaling"] == "strong"
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["kernel"] in ("classify_kernel", "emit_kernel") and 0 < r["frac"] < 1
+    assert "traffic_source" in r
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and len(c["repetitions_mvoxels_per_s"]) == 5
+    assert all(s >= 0.5 for s in c["repetition_seconds"])
+    assert c["min_mvoxels_per_s"] <= c["value"] <= c["max_mvoxels_per_s"]
+    assert c["cpu_share"]["affinity_cpus"] >= c["cores"]
+    # 256^3 perlin3d as 8 chunks of 128^3: the surface of the one-grid config (2 655 156 triangles with the CPU
+    # twin's samples; the device sampler differs from the twin by ~1e-7, which moves the samples that are
+    # zero in exact arithmetic -- the noise lattice points -- across the threshold: a few hundred triangles)
+    assert abs(j["triangles_total"] - 2655156) < 2000
+
+
+def test_strong_scaling_two_ranks_on_one_device():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", "bench.py", "--gpus", "2", "--grid", "256", "--steps", "3", "--warmup", "1"]
+    j = run(cmd, {"VTMC_BENCH_ONE_DEVICE": "1", "VTMC_BENCH_BACKEND": "gloo"})
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong"
+    assert j["config"]["chunks_per_gpu"] == 4 and "c -> rank c % 2" in j["config"]["workload"]
+    assert abs(j["triangles_total"] - 2655156) < 2000 and 0 < j["triangles_rank0"] < j["triangles_total"]
+    assert j["allgather_ms"]["avg"] >= 0 and j["cpu_baseline"] is None
+
+
+def test_stream_config_line():
+    j = run([sys.executable, "bench.py", "--config", "stream2048", "--grid", "256", "--batch", "3", "--steps", "1"])
+    assert j["n_gpus"] == 1 and j["config"]["chunks_per_gpu"] == 8 and j["config"]["kind"] == "fbm8"
+    assert j["value"] > 0 and j["triangles_total"] > 0
+    assert j["roofline"]["kernel"] in ("density_column_kernel", "classify_dense_kernel", "emit_kernel")
+    assert j["sampler_valu"]["frac"] > 0 and j["overlap_gain"] > 0

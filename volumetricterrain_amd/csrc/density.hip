@@ -99,52 +99,97 @@ __global__ __launch_bounds__(256) void density_generic_kernel(DensityLaunch dl, 
 // ----------------------------------------------------------------------------------------------
 // density_column_kernel -- the wave64 sampler (octaves <= 8).
 //
-// A lane owns one (fast, slow) column of the volume and walks it along y; the 64 lanes of a wave
-// are 64 consecutive points along the stride-1 axis, so every store is one coalesced 256-byte row.
-// What makes it cheap is what is UNIFORM or CONSTANT along that walk:
-//   * everything that depends on y alone (lattice cell, fraction, fade weight, the ramp) is the same
-//     for all lanes of the workgroup: it is computed once per (y, octave) into an LDS table and read
-//     back with one broadcast ds_read_b128;
-//   * inside one lattice cell the eight gradient dot products are linear in the y fraction and the
-//     x / z interpolation weights are constant, so the two x-z-interpolated faces of the cell collapse
-//     to S_j(t) = alpha_j + beta_j * t (j = low / high y face) and a sample is
+// A lane owns one column of the volume and walks it along the WALK axis; the lanes of a workgroup are
+// 256 consecutive points of the plane spanned by the other two axes, enumerated along the stride-1
+// axis first.  WALK is the axis with the largest stride when that is z (x-fastest volumes: the lane
+// plane is then one contiguous slab of memory and every step of a workgroup writes 1 KB of it), else
+// y (the C# z-fastest layout).  What makes the sampler cheap is what is UNIFORM or CONSTANT along
+// the walk:
+//   * everything that depends on the walk coordinate alone (lattice cell, fraction, fade weight,
+//     which octaves enter a new cell) is the same for every lane of every wave at that step: a small
+//     kernel writes it once per (volume, step) into a 128-byte row; a workgroup stages the rows of its
+//     segment in LDS once and every step reads its row back with six broadcast ds_read_b128 (scalar
+//     loads of the rows were tried first: one scalar-cache miss per step, ~900 cycles, stalls every wave
+//     of the workgroup at once and cannot be prefetched further than one row -- lgkmcnt is the only
+//     counter and scalar loads return out of order);
+//   * inside one lattice cell the eight gradient dot products are linear in the walk fraction t and
+//     the interpolation weights of the two lane axes are constant, so the two lane-interpolated faces
+//     of the cell collapse to S_j(t) = alpha_j + beta_j * t (j = low / high face) and a sample is
 //         noise = mix(fade(t), alpha_0 + beta_0 * t, alpha_1 + beta_1 * (t - 1))
 //     -- 5 VALU instructions per octave instead of 8 hashes + 8 gradients + 7 lerps;
-//   * the (alpha, beta) pairs are rebuilt only when the walk enters a new cell (a wave-uniform branch:
-//     all lanes share y); stepping into the next cell re-uses the high face as the new low face, so one
-//     face = 2 + 2 + 4 LDS lookups (permutation pairs, packed gradient offsets, gradient vectors).
-// Same noise definition as the per-sample kernel below and as oracle/density_ref.c; the x-z-y lerp
-// order and the fma contractions move results by a few 1e-7 (bar of the twin test: 2e-6).
-// VALU roofline: ~5 lane-ops per sample-octave + ~45 per face rebuild, see DESIGN.md.
+//   * the (alpha, beta) pairs are rebuilt only when the walk enters a new cell (wave-uniform: a bit of
+//     the row's mask word); stepping into the next cell re-uses the high face as the new low face, so
+//     one face = 8 LDS lookups (z walk: 4 hashes + 4 gradient vectors, the x-y part of the hash chain
+//     is constant along the walk; y walk: 2 + 2 + 4).
+// Same noise definition as the per-sample kernel above and as oracle/density_ref.c; the lerp order
+// (lane axes first, walk axis last) and the fma contractions move results by a few 1e-7 (bar of the
+// twin test: 2e-6).
 // ----------------------------------------------------------------------------------------------
-constexpr int kColSeg = 160;  // y samples per workgroup segment (table: kColSeg x (NOCT + 1) x 16 bytes)
+constexpr int kColSeg = 160;    // steps one workgroup walks before the next segment starts with a two-face rebuild (15 KB of rows in LDS)
+constexpr int kRowUsed = 24;    // dwords of a row the walk reads
+constexpr int kRowDwords = 32;  // [0..7] t, [8..15] fade(t), 16 ramp (y walk), 17 mask "next cell", 18 mask "rebuild both faces", 19/20 cell & 255 of octaves 0-3 / 4-7; 128-byte stride
+
+// one thread per (volume, step): the row of everything that depends on the walk coordinate alone
+__global__ __launch_bounds__(256) void density_row_kernel(DensityLaunch dl, const int *__restrict__ origins, int axis, int n_steps,
+                                                           int seg_len, float *__restrict__ rows)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= dl.n_volumes * n_steps) return;
+    const int vol = idx / n_steps, j = idx - vol * n_steps;
+    const float pw = (float)(origins[3 * vol + axis] + j);
+    float y = pw * dl.frequency, yp = (pw - 1.0f) * dl.frequency;
+    float *row = rows + (long long)idx * kRowDwords;
+    unsigned m1 = 0, m2 = 0, yc[2] = {0, 0};
+    for (int o = 0; o < 8; ++o) {
+        const float fy = floorf(y);
+        const int cell = (int)fy, prev = (int)floorf(yp);
+        const float t = y - fy;
+        row[o] = t;
+        row[8 + o] = fade(t);
+        if (o < dl.octaves) {
+            if (j % seg_len == 0 || (cell != prev && cell != prev + 1)) m2 |= 1u << o;   // first step of a walk, or a jump
+            else if (cell == prev + 1) m1 |= 1u << o;
+        }
+        yc[o >> 2] |= ((unsigned)cell & 255u) << (8 * (o & 3));
+        y *= dl.lacunarity;
+        yp *= dl.lacunarity;
+    }
+    row[16] = axis == 1 ? (pw - dl.ramp_center) * dl.ramp_scale : 0.f;
+    row[17] = __uint_as_float(m1);
+    row[18] = __uint_as_float(m2);
+    row[19] = __uint_as_float(yc[0]);
+    row[20] = __uint_as_float(yc[1]);
+    for (int q = 21; q < kRowDwords; ++q) row[q] = 0.f;
+}
 
 struct ColOct {
-    float a0, b0, a1, b1;  // faces j = 0, 1:  S_j(t) = a_j + b_j * t, already scaled by the octave's amplitude
-    float xr, zr, u, w;    // fractions and fade weights along the two lane axes
-    unsigned pxz;          // P(X) | P(X+1) << 8 | Z << 16
+    float a0, b0, a1, b1;  // faces j = 0, 1 in the cell's own fraction t:  S_0 = a0 + b0 * t,  S_1 = a1 + b1 * t  (a1 = alpha_1 - beta_1), scaled by the octave's amplitude
+    float ra, rb;          // fractions along the two lane axes (y walk: x, z; z walk: x, y)
+    unsigned key;          // y walk: P(X) | P(X+1) << 8 | Z << 16;  z walk: P(P(X+i)+Y+j) for (i,j) = 00, 01, 10, 11, one byte each
 };
 
-template <int NOCT>
-__global__ __launch_bounds__(256) void density_column_kernel(DensityLaunch dl, const unsigned char *__restrict__ perm,
-                                                              const int *__restrict__ origins, float *__restrict__ out,
-                                                              int fast_is_z, int n_plane_wgs, int n_yseg, int seg_len)
+// WALK = 1: along y, lane plane (x, z) or (z, x);  WALK = 2: along z, lane plane (x, y)
+template <int NOCT, int WALK>
+__global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl, const unsigned char *__restrict__ perm,
+                                                              const int *__restrict__ origins, const float *__restrict__ rows,
+                                                              float *__restrict__ out, int fast_is_z, int n_plane_wgs, int n_seg,
+                                                              int seg_len)
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     __shared__ unsigned short s_p2[256];  // P(i) | P(i+1) << 8
     __shared__ unsigned s_h2[256];        // byte offsets into s_grad of hash P(i) (low half) and P(i+1) (high half)
     __shared__ v4f s_grad[16];            // gradient of hash h as (gx, gy, gz, 0), components in {-1, 0, 1}
-    __shared__ float s_amp[8];
-    __shared__ v4f s_y[kColSeg][NOCT + 1];  // per (y, octave): {t, t - 1, fade(t), cell & 255 | flag << 8}; last: {ramp, 0, 0, 0}
+    __shared__ __attribute__((aligned(16))) float s_rows[kColSeg][kRowUsed];   // this segment's rows (96 of their 128 bytes)
 
     const int tid = threadIdx.x;
     unsigned r = blockIdx.x;
     const int pw = r % n_plane_wgs;
     r /= n_plane_wgs;
-    const int ys = r % n_yseg;
-    const int vol = r / n_yseg;
-    const int y_begin = ys * seg_len;
-    const int y_count = min(seg_len, dl.dy - y_begin);
+    const int seg = r % n_seg;
+    const int vol = r / n_seg;
+    const int n_steps = WALK == 1 ? dl.dy : dl.dz;
+    const int w_begin = seg * seg_len;
+    const int w_count = min(seg_len, n_steps - w_begin);
     const int ox = origins[3 * vol], oy = origins[3 * vol + 1], oz = origins[3 * vol + 2];
 
     {   // tables
@@ -159,126 +204,174 @@ __global__ __launch_bounds__(256) void density_column_kernel(DensityLaunch dl, c
             g[h < 4 ? 1 : ((h == 12 || h == 14) ? 0 : 2)] += sv;
             s_grad[h] = v4f{g[0], g[1], g[2], 0.f};
         }
-        if (tid == 0) {
-            float amp = 1.0f;
-            for (int o = 0; o < 8; ++o) {
-                s_amp[o] = amp;
-                amp *= dl.gain;
-            }
-        }
-        // y table: one entry per (y, octave); the previous sample's cell decides the flag
-        for (int e = tid; e < y_count * (NOCT + 1); e += 256) {
-            const int jj = e / (NOCT + 1), o = e - jj * (NOCT + 1);
-            const float py = (float)(oy + y_begin + jj);
-            if (o == NOCT) {
-                s_y[jj][NOCT] = v4f{(py - dl.ramp_center) * dl.ramp_scale, 0.f, 0.f, 0.f};
-                continue;
-            }
-            float y = py * dl.frequency, yp = (py - 1.0f) * dl.frequency;
-            for (int k = 0; k < o; ++k) {
-                y *= dl.lacunarity;
-                yp *= dl.lacunarity;
-            }
-            const float fy = floorf(y);
-            const int cell = (int)fy, prev = (int)floorf(yp);
-            const float t = y - fy;
-            const unsigned flag = jj == 0 ? 2u : (cell == prev ? 0u : (cell == prev + 1 ? 1u : 2u));
-            s_y[jj][o] = v4f{t, t - 1.0f, fade(t), __uint_as_float(((unsigned)cell & 255u) | (flag << 8))};
+        // the segment's rows: everything that depends on the walk coordinate alone, staged once per workgroup
+        const float *src = rows + ((long long)vol * n_steps + w_begin) * kRowDwords;
+        for (int e = tid; e < w_count * kRowUsed; e += 256) {
+            const int rr = e / kRowUsed, cc = e - rr * kRowUsed;
+            s_rows[rr][cc] = src[rr * kRowDwords + cc];
         }
     }
     __syncthreads();
 
-    // this lane's column
-    const int dfast = fast_is_z ? dl.dz : dl.dx;
-    const int dslow = fast_is_z ? dl.dx : dl.dz;
-    const long long q = (long long)pw * 256 + tid;
-    const bool live = q < (long long)dfast * dslow;
-    const long long qc = live ? q : 0;
-    const int a = (int)(qc % dfast), c = (int)(qc / dfast);
-    const int i = fast_is_z ? c : a, k = fast_is_z ? a : c;
-    float x = (float)(ox + i) * dl.frequency, z = (float)(oz + k) * dl.frequency;
+    // this lane's column: (i, j, k) of its first sample
+    int i, j, k;
+    bool live;
+    {
+        const long long q = (long long)pw * 256 + tid;
+        if (WALK == 1) {
+            const int dfast = fast_is_z ? dl.dz : dl.dx, dslow = fast_is_z ? dl.dx : dl.dz;
+            live = q < (long long)dfast * dslow;
+            const long long qc = live ? q : 0;
+            const int a = (int)(qc % dfast), c = (int)(qc / dfast);
+            i = fast_is_z ? c : a;
+            j = w_begin;
+            k = fast_is_z ? a : c;
+        } else {
+            live = q < (long long)dl.dx * dl.dy;
+            const long long qc = live ? q : 0;
+            i = (int)(qc % dl.dx);
+            j = (int)(qc / dl.dx);
+            k = w_begin;
+        }
+    }
+    // lane axes A, B: (x, z) for the y walk, (x, y) for the z walk
+    float pa = (float)(ox + i) * dl.frequency, pb = (WALK == 1 ? (float)(oz + k) : (float)(oy + j)) * dl.frequency;
+    const float lane_ramp = WALK == 1 ? 0.f : ((float)(oy + j) - dl.ramp_center) * dl.ramp_scale;
 
     ColOct st[NOCT];
+    float amp[NOCT];
+    {
+        float am = 1.0f;
 #pragma unroll
-    for (int o = 0; o < NOCT; ++o) {
-        const float fx = floorf(x), fz = floorf(z);
-        const unsigned X = (unsigned)(int)fx & 255u, Z = (unsigned)(int)fz & 255u;
-        st[o].xr = x - fx;
-        st[o].zr = z - fz;
-        st[o].u = fade(st[o].xr);
-        st[o].w = fade(st[o].zr);
-        st[o].pxz = (unsigned)s_p2[X] | (Z << 16);
-        st[o].a0 = st[o].b0 = st[o].a1 = st[o].b1 = 0.f;
-        x *= dl.lacunarity;
-        z *= dl.lacunarity;
+        for (int o = 0; o < NOCT; ++o) {
+            const float fa = floorf(pa), fb = floorf(pb);
+            const unsigned A = (unsigned)(int)fa & 255u, B = (unsigned)(int)fb & 255u;
+            st[o].ra = pa - fa;
+            st[o].rb = pb - fb;
+            const unsigned px = s_p2[A];   // P(X) | P(X+1) << 8
+            if (WALK == 1) {
+                st[o].key = px | (B << 16);
+            } else {   // the x-y part of the hash chain is constant along a z walk
+                const unsigned q0 = s_p2[((px & 255u) + B) & 255u], q1 = s_p2[((px >> 8) + B) & 255u];
+                st[o].key = q0 | (q1 << 16);
+            }
+            st[o].a0 = st[o].b0 = st[o].a1 = st[o].b1 = 0.f;
+            amp[o] = am;   // wave-uniform: the compiler keeps these in SGPRs
+            pa *= dl.lacunarity;
+            pb *= dl.lacunarity;
+            am *= dl.gain;
+        }
     }
 
-    // one face of the cell: the four corners (i, k) at lattice row Yp, interpolated in x then z
-    auto face = [&](const ColOct &s, unsigned Yp, float amp, float &alpha, float &beta) {
-        const unsigned Z = s.pxz >> 16;
-        const unsigned pa = s_p2[((s.pxz & 255u) + Yp) & 255u] & 255u;         // P(P(X) + Yp)
-        const unsigned pb = s_p2[(((s.pxz >> 8) & 255u) + Yp) & 255u] & 255u;  // P(P(X+1) + Yp)
-        const unsigned ha = s_h2[(pa + Z) & 255u], hb = s_h2[(pb + Z) & 255u];
+    // one face of the cell: the four corners over the lane axes at lattice row Wp of the walk axis,
+    // interpolated along A then B.  The inputs pass through an empty asm statement so that nothing
+    // derived from them is hoisted out of the walk for all octaves at once (~50 VGPRs otherwise).
+    auto face = [&](const ColOct &s, unsigned Wp, float am, float &alpha, float &beta) {
+        float ra = s.ra, rb = s.rb;
+        unsigned key = s.key;
+        asm volatile("" : "+v"(ra), "+v"(rb), "+v"(key));
         const char *gb = reinterpret_cast<const char *>(s_grad);
-        const v4f g00 = *reinterpret_cast<const v4f *>(gb + (ha & 0xFFFFu)), g01 = *reinterpret_cast<const v4f *>(gb + (ha >> 16));
-        const v4f g10 = *reinterpret_cast<const v4f *>(gb + (hb & 0xFFFFu)), g11 = *reinterpret_cast<const v4f *>(gb + (hb >> 16));
-        const float x0 = s.xr, x1 = s.xr - 1.0f, z0 = s.zr, z1 = s.zr - 1.0f;
-        const float c00 = __builtin_fmaf(g00.z, z0, g00.x * x0), c10 = __builtin_fmaf(g10.z, z0, g10.x * x1);
-        const float c01 = __builtin_fmaf(g01.z, z1, g01.x * x0), c11 = __builtin_fmaf(g11.z, z1, g11.x * x1);
-        const float cu0 = __builtin_fmaf(s.u, c10 - c00, c00), cu1 = __builtin_fmaf(s.u, c11 - c01, c01);
-        const float bu0 = __builtin_fmaf(s.u, g10.y - g00.y, g00.y), bu1 = __builtin_fmaf(s.u, g11.y - g01.y, g01.y);
-        alpha = amp * __builtin_fmaf(s.w, cu1 - cu0, cu0);
-        beta = amp * __builtin_fmaf(s.w, bu1 - bu0, bu0);
+        v4f g00, g01, g10, g11;   // g[a-corner][b-corner]
+        if (WALK == 1) {
+            const unsigned Z = key >> 16;
+            const unsigned p0 = s_p2[((key & 255u) + Wp) & 255u] & 255u;         // P(P(X) + Y)
+            const unsigned p1 = s_p2[(((key >> 8) & 255u) + Wp) & 255u] & 255u;  // P(P(X+1) + Y)
+            const unsigned h0 = s_h2[(p0 + Z) & 255u], h1 = s_h2[(p1 + Z) & 255u];
+            g00 = *reinterpret_cast<const v4f *>(gb + (h0 & 0xFFFFu));
+            g01 = *reinterpret_cast<const v4f *>(gb + (h0 >> 16));
+            g10 = *reinterpret_cast<const v4f *>(gb + (h1 & 0xFFFFu));
+            g11 = *reinterpret_cast<const v4f *>(gb + (h1 >> 16));
+        } else {
+            g00 = *reinterpret_cast<const v4f *>(gb + (s_h2[((key & 255u) + Wp) & 255u] & 0xFFFFu));
+            g01 = *reinterpret_cast<const v4f *>(gb + (s_h2[(((key >> 8) & 255u) + Wp) & 255u] & 0xFFFFu));
+            g10 = *reinterpret_cast<const v4f *>(gb + (s_h2[(((key >> 16) & 255u) + Wp) & 255u] & 0xFFFFu));
+            g11 = *reinterpret_cast<const v4f *>(gb + (s_h2[((key >> 24) + Wp) & 255u] & 0xFFFFu));
+        }
+        const float u = fade(ra), v = fade(rb);
+        const float a0 = ra, a1 = ra - 1.0f, b0 = rb, b1 = rb - 1.0f;
+        // gradient components: A is always x; B is z (y walk) or y (z walk); the walk component is the other one
+        auto gB = [](const v4f &g) { return WALK == 1 ? g.z : g.y; };
+        auto gW = [](const v4f &g) { return WALK == 1 ? g.y : g.z; };
+        const float c00 = __builtin_fmaf(gB(g00), b0, g00.x * a0), c10 = __builtin_fmaf(gB(g10), b0, g10.x * a1);
+        const float c01 = __builtin_fmaf(gB(g01), b1, g01.x * a0), c11 = __builtin_fmaf(gB(g11), b1, g11.x * a1);
+        const float cu0 = __builtin_fmaf(u, c10 - c00, c00), cu1 = __builtin_fmaf(u, c11 - c01, c01);
+        const float bu0 = __builtin_fmaf(u, gW(g10) - gW(g00), gW(g00)), bu1 = __builtin_fmaf(u, gW(g11) - gW(g01), gW(g01));
+        alpha = am * __builtin_fmaf(v, cu1 - cu0, cu0);
+        beta = am * __builtin_fmaf(v, bu1 - bu0, bu0);
     };
 
-    float *dst = out + vol * dl.sv + (long long)i * dl.sx + (long long)y_begin * dl.sy + (long long)k * dl.sz;
-    for (int jj = 0; jj < y_count; ++jj) {
+    float *dst = out + vol * dl.sv + (long long)i * dl.sx + (long long)j * dl.sy + (long long)k * dl.sz;
+    const long long dst_step = WALK == 1 ? dl.sy : dl.sz;
+    for (int jj = 0; jj < w_count; ++jj) {
+        // the step's row: six broadcast reads (every lane the same address)
+        const v4f *rp = reinterpret_cast<const v4f *>(s_rows[jj]);
+        const v4f ta = rp[0], tb = rp[1], va = rp[2], vb = rp[3], ma = rp[4];
+        const float t[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+        const float fv[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        const unsigned m1 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.y)), m2 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.z));
+        if (m1 | m2) {   // some octave enters a new lattice cell at this step (the same for every lane: wave-uniform)
+            const unsigned wc[2] = {(unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(ma.w)),
+                                    (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_rows[jj][20]))};
+#pragma unroll
+            for (int o = 0; o < NOCT; ++o) {
+                if ((m1 | m2) & (1u << o)) {
+                    const unsigned W = (wc[o >> 2] >> (8 * (o & 3))) & 255u;
+                    if (m2 & (1u << o)) {
+                        face(st[o], W, amp[o], st[o].a0, st[o].b0);
+                    } else {   // the high face of the cell just left is the low face of this one: alpha_0 = alpha_1, back from the t - 1 form
+                        st[o].a0 = st[o].a1 + st[o].b1;
+                        st[o].b0 = st[o].b1;
+                    }
+                    float al, be;
+                    face(st[o], W + 1u, amp[o], al, be);
+                    st[o].a1 = al - be;   // alpha_1 + beta_1 * (t - 1) = (alpha_1 - beta_1) + beta_1 * t: both faces read the same t
+                    st[o].b1 = be;
+                }
+            }
+        }
         float sum = 0.0f;
 #pragma unroll
         for (int o = 0; o < NOCT; ++o) {
-            if (o < dl.octaves) {
-                const v4f e = s_y[jj][o];
-                const unsigned bits = __builtin_amdgcn_readfirstlane(__float_as_uint(e.w));
-                if (bits >> 8) {  // the walk entered a new lattice cell (same y for every lane: wave-uniform)
-                    const unsigned Y = bits & 255u;
-                    const float amp = s_amp[o];
-                    if ((bits >> 8) == 1u) {
-                        st[o].a0 = st[o].a1;
-                        st[o].b0 = st[o].b1;
-                    } else {
-                        face(st[o], Y, amp, st[o].a0, st[o].b0);
-                    }
-                    face(st[o], Y + 1u, amp, st[o].a1, st[o].b1);
-                }
-                const float s0 = __builtin_fmaf(st[o].b0, e.x, st[o].a0), s1 = __builtin_fmaf(st[o].b1, e.y, st[o].a1);
-                sum += __builtin_fmaf(e.z, s1 - s0, s0);
-            }
+            const float s0 = __builtin_fmaf(st[o].b0, t[o], st[o].a0), s1 = __builtin_fmaf(st[o].b1, t[o], st[o].a1);
+            sum += __builtin_fmaf(fv[o], s1 - s0, s0);
         }
-        const float ramp = s_y[jj][NOCT].x;
-        if (live) *dst = sum - ramp;
-        dst += dl.sy;
+        if (live && (!(dl.ablate & 1) || sum == 1e30f)) *dst = sum - (WALK == 1 ? ma.x : lane_ramp);   // ablate 1: diagnostics, no stores
+        dst += dst_step;
     }
 }
 
 hipError_t launch_density(const DensityLaunch &dl, const unsigned char *d_perm, const int *d_origins,
-                          float *d_out, hipStream_t stream)
+                          float *d_rows, float *d_out, hipStream_t stream)
 {
     const int fast_is_z = (dl.sz == 1 && dl.sx != 1) ? 1 : 0;
     const int dfast = fast_is_z ? dl.dz : dl.dx;
     const int dslow = fast_is_z ? dl.dx : dl.dz;
     if (dl.octaves <= 8) {
-        const long long plane = (long long)dfast * dslow;
+        // walk along z when the lane plane (x, y) is then contiguous in memory, else along y
+        const bool walk_z = dl.sx == 1 && dl.sy == dl.dx && dl.sz >= (long long)dl.dx * dl.dy;
+        const int n_steps = walk_z ? dl.dz : dl.dy;
+        const long long plane = walk_z ? (long long)dl.dx * dl.dy : (long long)dfast * dslow;
         const long long n_plane_wgs = (plane + 255) / 256;
-        const int n_yseg = (dl.dy + kColSeg - 1) / kColSeg;
-        const int seg_len = (dl.dy + n_yseg - 1) / n_yseg;  // equal segments: every one pays the same two-face start-up
-        const long long n_wgs = n_plane_wgs * n_yseg * dl.n_volumes;
-        if (n_wgs <= 0 || n_wgs > 0x7fffffffll) return hipErrorInvalidValue;
-        if (dl.octaves == 1)
-            hipLaunchKernelGGL((density_column_kernel<1>), dim3((unsigned)n_wgs), dim3(256), 0, stream, dl, d_perm, d_origins, d_out,
-                               fast_is_z, (int)n_plane_wgs, n_yseg, seg_len);
-        else
-            hipLaunchKernelGGL((density_column_kernel<8>), dim3((unsigned)n_wgs), dim3(256), 0, stream, dl, d_perm, d_origins, d_out,
-                               fast_is_z, (int)n_plane_wgs, n_yseg, seg_len);
+        const int n_seg = (n_steps + kColSeg - 1) / kColSeg;
+        const int seg_len = (n_steps + n_seg - 1) / n_seg;  // equal segments: every one pays the same two-face start-up
+        const long long n_wgs = n_plane_wgs * n_seg * dl.n_volumes;
+        const long long n_rows = (long long)dl.n_volumes * n_steps;
+        if (n_wgs <= 0 || n_wgs > 0x7fffffffll || n_rows > 0x7fffffffll) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(density_row_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, dl, d_origins, walk_z ? 2 : 1,
+                           n_steps, seg_len, d_rows);
+#define VTMC_COL(N)                                                                                                                   \
+    case N:                                                                                                                           \
+        if (walk_z)                                                                                                                   \
+            hipLaunchKernelGGL((density_column_kernel<N, 2>), dim3((unsigned)n_wgs), dim3(256), 0, stream, dl, d_perm, d_origins, d_rows, \
+                               d_out, fast_is_z, (int)n_plane_wgs, n_seg, seg_len);                                                  \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((density_column_kernel<N, 1>), dim3((unsigned)n_wgs), dim3(256), 0, stream, dl, d_perm, d_origins, d_rows, \
+                               d_out, fast_is_z, (int)n_plane_wgs, n_seg, seg_len);                                                  \
+        break;
+        switch (dl.octaves) {   // the octave count is a template parameter: the eight octaves of a sample are straight-line code
+            VTMC_COL(1) VTMC_COL(2) VTMC_COL(3) VTMC_COL(4) VTMC_COL(5) VTMC_COL(6) VTMC_COL(7) VTMC_COL(8)
+        }
+#undef VTMC_COL
         return hipGetLastError();
     }
     const int nseg = (dfast + 255) / 256;
@@ -288,5 +381,7 @@ hipError_t launch_density(const DensityLaunch &dl, const unsigned char *d_perm, 
                        fast_is_z, nseg);
     return hipGetLastError();
 }
+
+size_t density_rows_bytes(int n_volumes, int dy, int dz) { return (size_t)n_volumes * (size_t)(dy > dz ? dy : dz) * kRowDwords * sizeof(float); }
 
 }  // namespace vtmc

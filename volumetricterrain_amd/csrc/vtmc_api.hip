@@ -340,7 +340,7 @@ int32_t vtmc_destroy(vtmc_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     comm_release(ctx);
     for (DevBuf *b : {&ctx->d_vert, &ctx->d_trinum, &ctx->counts, &ctx->offsets, &ctx->active, &ctx->partials, &ctx->totals,
-                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->terrain, &ctx->heightmap,
+                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->yrows, &ctx->terrain, &ctx->heightmap,
                       &ctx->vcounts, &ctx->voffsets, &ctx->vpartials, &ctx->vtotals, &ctx->verts, &ctx->indices, &ctx->chunk_image,
                       &ctx->comm_send})
         release(*b);
@@ -670,6 +670,7 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     else if (k == "emit_ablate") ctx->tune.emit_ablate = value;
     else if (k == "classify_ablate") ctx->tune.classify_ablate = value;
     else if (k == "emit_row_masks") ctx->tune.emit_row_masks = value;
+    else if (k == "density_ablate") ctx->tune.density_ablate = value;
     else if (k == "emit_group_log2") ctx->tune.emit_group_log2 = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (k == "emit_wgs_per_cu") ctx->tune.emit_wgs_per_cu = value;
     else return fail(ctx, VTMC_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
@@ -914,8 +915,11 @@ int32_t vtmc_density_fill_device_async(vtmc_ctx *ctx, const vtmc_density_params 
         ctx->perm_seed = params->seed;
         ctx->perm_valid = true;
     }
-    if (ctx->origins.bytes < sizeof(int32_t) * 3 * (size_t)n_volumes) VTMC_HIP(ctx, hipStreamSynchronize(st));  // about to reallocate
+    const size_t rows_bytes = density_rows_bytes(n_volumes, dim_y, dim_z);
+    if (ctx->origins.bytes < sizeof(int32_t) * 3 * (size_t)n_volumes || ctx->yrows.bytes < rows_bytes)
+        VTMC_HIP(ctx, hipStreamSynchronize(st));  // about to reallocate
     if (int rc = ensure(ctx, ctx->origins, sizeof(int32_t) * 3 * (size_t)n_volumes)) return rc;
+    if (int rc = ensure(ctx, ctx->yrows, rows_bytes)) return rc;
     // stream-ordered behind any earlier fill of this context that still reads the previous origins
     VTMC_HIP(ctx, hipMemcpyAsync(ctx->origins.p, origins, sizeof(int32_t) * 3 * (size_t)n_volumes, hipMemcpyHostToDevice, st));
     // the caller's array is only borrowed for this call: wait for that small copy (and for nothing queued after it)
@@ -936,8 +940,9 @@ int32_t vtmc_density_fill_device_async(vtmc_ctx *ctx, const vtmc_density_params 
     dl.sz = stride_z;
     dl.sv = volume_stride;
     dl.n_volumes = n_volumes;
+    dl.ablate = ctx->tune.density_ablate;
     VTMC_HIP(ctx, hipEventRecord(ctx->ev_fill[0], st));
-    VTMC_HIP(ctx, launch_density(dl, (const unsigned char *)ctx->perm.p, (const int *)ctx->origins.p, d_out, st));
+    VTMC_HIP(ctx, launch_density(dl, (const unsigned char *)ctx->perm.p, (const int *)ctx->origins.p, (float *)ctx->yrows.p, d_out, st));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev_fill[1], st));
     ctx->fill_timed = true;
     return VTMC_OK;

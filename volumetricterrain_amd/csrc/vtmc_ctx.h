@@ -30,7 +30,7 @@ struct vtmc_ctx {
     hipStream_t stream = nullptr;
     vtmc::DeviceTables tables{nullptr, nullptr};
     VtmcDevBuf d_vert, d_trinum;
-    VtmcDevBuf counts, offsets, active, partials, totals, volcounts, cases, tris, input, list, perm, origins;
+    VtmcDevBuf counts, offsets, active, partials, totals, volcounts, cases, tris, input, list, perm, origins, yrows;
     VtmcDevBuf vcounts, voffsets, vpartials, vtotals, verts, indices;  // indexed output
     int output_mode = VTMC_OUTPUT_SOUP;
     bool last_indexed = false;

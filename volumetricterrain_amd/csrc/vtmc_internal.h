@@ -60,6 +60,7 @@ struct Tuning {
     int classify_ablate = 0;  // diagnostics only: 1 no halo rows (output invalid)
     int emit_row_masks = 1;   // emit loads only the tile rows next to cells with triangles (masks from classify)
     int emit_group_log2 = 0;  // each wave takes 2^g consecutive active-list entries per round
+    int density_ablate = 0;   // diagnostics only: 1 the sampler skips its stores (output invalid)
 };
 
 // scan scratch layout
@@ -111,9 +112,12 @@ struct DensityLaunch {
     int dx, dy, dz;
     long long sx, sy, sz, sv;
     int n_volumes;
+    int ablate;  // diagnostics only (vtmc_set_tuning "density_ablate"): 1 skip the stores (output invalid)
 };
+// d_rows: density_rows_bytes(n_volumes, dy, dz) bytes of scratch (the per-(volume, step) rows of the column sampler)
 hipError_t launch_density(const DensityLaunch &dl, const unsigned char *d_perm, const int *d_origins,
-                          float *d_out, hipStream_t stream);
+                          float *d_rows, float *d_out, hipStream_t stream);
+size_t density_rows_bytes(int n_volumes, int dy, int dz);
 void density_permutation(uint64_t seed, unsigned char perm[256]);
 
 }  // namespace vtmc
