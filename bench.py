@@ -25,7 +25,9 @@ timed on this box's host cores on a bounded sample of the same device-generated 
 """
 import os
 
-# the CPU leg pins its OpenMP threads; libgomp reads these when it is first mapped (import torch)
+# the CPU leg pins its OpenMP threads; libgomp reads these when it is first mapped (import torch) and
+# binds THIS thread to the first place from then on -- so the process's CPU share is read before that
+_AFFINITY_AT_START = sorted(os.sched_getaffinity(0))
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
 
@@ -90,7 +92,7 @@ def _cpu_model():
 def cpu_share():
     """Physical cores this process may use: /proc/cpuinfo (physical id, core id) pairs of the CPUs in
     sched_getaffinity, capped by the cgroup's cpu.max quota when one is set."""
-    aff = sorted(os.sched_getaffinity(0))
+    aff = _AFFINITY_AT_START
     cores, cur = {}, {}
     try:
         for line in open("/proc/cpuinfo"):

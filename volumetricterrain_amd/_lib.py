@@ -86,7 +86,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.build()
+    path = os.environ.get("VTMC_LIB") or _build.build()   # VTMC_LIB: A/B of two builds on one box (tools/ab_bench.py)
     # PyTorch wheels bundle their own libamdhip64; if this process is going to use torch as well
     # (device memory, streams, torch.distributed), torch must load first so both bind to ONE HIP
     # runtime -- loaded the other way round torch.cuda reports no device.

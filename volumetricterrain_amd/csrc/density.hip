@@ -125,9 +125,9 @@ __global__ __launch_bounds__(256) void density_generic_kernel(DensityLaunch dl, 
 // (lane axes first, walk axis last) and the fma contractions move results by a few 1e-7 (bar of the
 // twin test: 2e-6).
 // ----------------------------------------------------------------------------------------------
-constexpr int kColSeg = 160;    // steps one workgroup walks before the next segment starts with a two-face rebuild (15 KB of rows in LDS)
-constexpr int kRowUsed = 24;    // dwords of a row the walk reads
-constexpr int kRowDwords = 32;  // [0..7] t, [8..15] fade(t), 16 ramp (y walk), 17 mask "next cell", 18 mask "rebuild both faces", 19/20 cell & 255 of octaves 0-3 / 4-7; 128-byte stride
+constexpr int kColSeg = 160;    // steps one workgroup walks before the next segment starts with a two-face rebuild (20 KB of rows in LDS)
+constexpr int kRowUsed = 32;    // dwords of a row the walk reads
+constexpr int kRowDwords = 32;  // [0..7] t, [8..15] fade(t), [16..23] t - 1, 24 ramp (y walk), 25 mask "next cell", 26 mask "rebuild both faces", 27/28 cell & 255 of octaves 0-3 / 4-7
 
 // one thread per (volume, step): the row of everything that depends on the walk coordinate alone
 __global__ __launch_bounds__(256) void density_row_kernel(DensityLaunch dl, const int *__restrict__ origins, int axis, int n_steps,
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void density_row_kernel(DensityLaunch dl, cons
         const float t = y - fy;
         row[o] = t;
         row[8 + o] = fade(t);
+        row[16 + o] = t - 1.0f;
         if (o < dl.octaves) {
             if (j % seg_len == 0 || (cell != prev && cell != prev + 1)) m2 |= 1u << o;   // first step of a walk, or a jump
             else if (cell == prev + 1) m1 |= 1u << o;
@@ -154,16 +155,17 @@ __global__ __launch_bounds__(256) void density_row_kernel(DensityLaunch dl, cons
         y *= dl.lacunarity;
         yp *= dl.lacunarity;
     }
-    row[16] = axis == 1 ? (pw - dl.ramp_center) * dl.ramp_scale : 0.f;
-    row[17] = __uint_as_float(m1);
-    row[18] = __uint_as_float(m2);
-    row[19] = __uint_as_float(yc[0]);
-    row[20] = __uint_as_float(yc[1]);
-    for (int q = 21; q < kRowDwords; ++q) row[q] = 0.f;
+    row[24] = axis == 1 ? (pw - dl.ramp_center) * dl.ramp_scale : 0.f;
+    row[25] = __uint_as_float(m1);
+    row[26] = __uint_as_float(m2);
+    row[27] = __uint_as_float(yc[0]);
+    row[28] = __uint_as_float(yc[1]);
+    for (int q = 29; q < kRowDwords; ++q) row[q] = 0.f;
 }
 
 struct ColOct {
-    float a0, b0, a1, b1;  // faces j = 0, 1 in the cell's own fraction t:  S_0 = a0 + b0 * t,  S_1 = a1 + b1 * t  (a1 = alpha_1 - beta_1), scaled by the octave's amplitude
+    float a0, b0, a1, b1;  // faces j = 0, 1:  S_0 = a0 + b0 * t,  S_1 = a1 + b1 * (t - 1), scaled by the octave's amplitude.  Each pair is a
+                           // pure function of (column, lattice row, octave) -- a sample never depends on where its walk started
     float ra, rb;          // fractions along the two lane axes (y walk: x, z; z walk: x, y)
     unsigned key;          // y walk: P(X) | P(X+1) << 8 | Z << 16;  z walk: P(P(X+i)+Y+j) for (i,j) = 00, 01, 10, 11, one byte each
 };
@@ -305,34 +307,32 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
     for (int jj = 0; jj < w_count; ++jj) {
         // the step's row: six broadcast reads (every lane the same address)
         const v4f *rp = reinterpret_cast<const v4f *>(s_rows[jj]);
-        const v4f ta = rp[0], tb = rp[1], va = rp[2], vb = rp[3], ma = rp[4];
+        const v4f ta = rp[0], tb = rp[1], va = rp[2], vb = rp[3], ua = rp[4], ub = rp[5], ma = rp[6];
         const float t[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
         const float fv[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        const float t1[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};
         const unsigned m1 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.y)), m2 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.z));
         if (m1 | m2) {   // some octave enters a new lattice cell at this step (the same for every lane: wave-uniform)
             const unsigned wc[2] = {(unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(ma.w)),
-                                    (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_rows[jj][20]))};
+                                    (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_rows[jj][28]))};
 #pragma unroll
             for (int o = 0; o < NOCT; ++o) {
                 if ((m1 | m2) & (1u << o)) {
                     const unsigned W = (wc[o >> 2] >> (8 * (o & 3))) & 255u;
                     if (m2 & (1u << o)) {
                         face(st[o], W, amp[o], st[o].a0, st[o].b0);
-                    } else {   // the high face of the cell just left is the low face of this one: alpha_0 = alpha_1, back from the t - 1 form
-                        st[o].a0 = st[o].a1 + st[o].b1;
+                    } else {   // the high face of the cell just left is the low face of this one, bit for bit
+                        st[o].a0 = st[o].a1;
                         st[o].b0 = st[o].b1;
                     }
-                    float al, be;
-                    face(st[o], W + 1u, amp[o], al, be);
-                    st[o].a1 = al - be;   // alpha_1 + beta_1 * (t - 1) = (alpha_1 - beta_1) + beta_1 * t: both faces read the same t
-                    st[o].b1 = be;
+                    face(st[o], W + 1u, amp[o], st[o].a1, st[o].b1);
                 }
             }
         }
         float sum = 0.0f;
 #pragma unroll
         for (int o = 0; o < NOCT; ++o) {
-            const float s0 = __builtin_fmaf(st[o].b0, t[o], st[o].a0), s1 = __builtin_fmaf(st[o].b1, t[o], st[o].a1);
+            const float s0 = __builtin_fmaf(st[o].b0, t[o], st[o].a0), s1 = __builtin_fmaf(st[o].b1, t1[o], st[o].a1);
             sum += __builtin_fmaf(fv[o], s1 - s0, s0);
         }
         if (live && (!(dl.ablate & 1) || sum == 1e30f)) *dst = sum - (WALK == 1 ? ma.x : lane_ramp);   // ablate 1: diagnostics, no stores

@@ -22,13 +22,14 @@ constexpr int kTriDwords = 19;     // 76-byte record
 //     north-star bar is 1e-5), !FAST is bit-compatible with the CPU oracle.
 // ----------------------------------------------------------------------------------------------
 constexpr int kSlotCap = 384;  // triangle slots kept before a flush (a step adds at most 320)
+constexpr int kStageTris = 33; // records staged at a time: half a batch + 1 -- 9.6 KB of LDS per wave, four workgroups per CU
 
 struct __attribute__((aligned(16))) EmitLds2 {
     float tile[1000];
     unsigned slot[kSlotCap];        // triangle slot -> cell | edge triple << 9
     unsigned short acell[512];      // active cells of the block, ascending cell id
     unsigned char cases[512];
-    float stage[64 * kTriDwords + 4];
+    float stage[kStageTris * kTriDwords + 4];
 };
 static_assert(sizeof(EmitLds2) % 16 == 0 && offsetof(EmitLds2, stage) % 16 == 0, "stage must stay 16-byte aligned");
 
@@ -102,6 +103,27 @@ __device__ __forceinline__ void normalise(float d[3])
     }
 }
 
+// Streams the staged dwords [lo, hi) (stream coordinates: stage[i] goes to gal[i], gal 16-byte aligned)
+// with 16-byte non-temporal stores; the < 4 dwords before the first whole quad and after the last go
+// out as single dwords from lanes 0-3 / 4-7.
+__device__ __forceinline__ void stream_out_range(const float *stage, float *__restrict__ gal, int lo, int hi, int lane, int ablate)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int body_lo = (lo + 3) & ~3, body_hi = hi & ~3;
+    if (!(ablate & 1)) {
+        for (int q4 = body_lo + 4 * lane; q4 < body_hi; q4 += 256) {
+            const v4f v = *reinterpret_cast<const v4f *>(stage + q4);
+            v4f *p = reinterpret_cast<v4f *>(gal + q4);
+            if (ablate & 16) __builtin_nontemporal_store(v, p);   // diagnostics: streaming hint (4 % slower at four workgroups per CU)
+            else *p = v;
+        }
+    }
+    const int k = lane & 3;
+    const int idx = lane < 4 ? lo + k : body_hi + k;
+    const bool on = lane < 4 ? (idx < body_lo && idx < hi) : (lane < 8 && idx < hi && idx >= body_lo);
+    if (on) __builtin_nontemporal_store(stage[idx], gal + idx);
+}
+
 // One lane per triangle.  Vertex = position along the edge (MarchingCube.compute:128-133: t =
 // -cube[a] / (cube[b] - cube[a]), lerp with v-u = +-1 on the edge axis and 0 on the others) and the
 // trilinear normal fetch of MarchingCube.compute:69-99, which on a lattice edge is a 2-point lerp
@@ -115,6 +137,9 @@ __device__ __forceinline__ void emit_flush2(EmitLds2 *L, int pending, size_t tri
         const int s = s0 + lane;
         const size_t d0 = (tri_base + (size_t)s0) * kTriDwords;  // first global dword of this batch
         const int sh = (int)(d0 & 3);                            // staging shift = global misalignment
+        float rec[18];
+#pragma unroll
+        for (int c = 0; c < 18; ++c) rec[c] = 0.f;
         if (s < pending && !(ablate & 4)) {
             const unsigned sc = L->slot[s];
             const int cell = sc & 511u;
@@ -147,7 +172,6 @@ __device__ __forceinline__ void emit_flush2(EmitLds2 *L, int pending, size_t tri
                 lattice_gradient(tile, l0, g0[k]);
                 lattice_gradient(tile, l1, g1[k]);
             }
-            float *rec = L->stage + sh + lane * kTriDwords;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 normalise<FAST>(g0[k]);
@@ -159,25 +183,30 @@ __device__ __forceinline__ void emit_flush2(EmitLds2 *L, int pending, size_t tri
                                               : g0[k][c] + w[k] * (g1[k][c] - g0[k][c]);
                 }
             }
-            rec[18] = __int_as_float(block_id);
         }
-        VTMC_WAVE_SYNC();
+        // The 64 records of the batch leave through a staging area of 33, in two rounds.  In stream
+        // coordinates (dwords from the 16-byte aligned address below the batch) record r sits at
+        // sh + 19 r; round 0 stages records 0..32 and stores every whole quad below 608 + (sh ? 4 : 0),
+        // round 1 stages records 32..63 (record 32 again, so the quad that straddles the two halves left
+        // complete in round 0) and continues from that quad boundary: no partial stores in mid-batch.
         const int cnt = pending - s0 < 64 ? pending - s0 : 64;
-        const int lo = sh, hi = sh + cnt * kTriDwords;
         float *gal = out + (d0 - sh);  // 16-byte aligned
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        // body: whole 16-byte quads, no per-element predicates (write-once stream: non-temporal)
-        const int body_lo = (lo + 3) & ~3, body_hi = hi & ~3;
-        if (!(ablate & 1)) {
-            for (int q4 = body_lo + 4 * lane; q4 < body_hi; q4 += 256)
-                __builtin_nontemporal_store(*reinterpret_cast<const v4f *>(L->stage + q4), reinterpret_cast<v4f *>(gal + q4));
-        }
-        // head (< 4 dwords before the first whole quad) and tail (< 4 after the last): lanes 0-3 / 4-7
-        {
-            const int k = lane & 3;
-            const int idx = lane < 4 ? lo + k : body_hi + k;
-            const bool on = lane < 4 ? (idx < body_lo && idx < hi) : (lane < 8 && idx < hi && idx >= body_lo);
-            if (on) __builtin_nontemporal_store(L->stage[idx], gal + idx);
+        const int split = 32 * kTriDwords + (sh ? 4 : 0);   // multiple of 4
+        const int end = sh + cnt * kTriDwords;
+        for (int h = 0; h == 0 || cnt > 32 * h; ++h) {   // wave-uniform, at most two rounds
+            VTMC_WAVE_SYNC();
+            const int r = lane - 32 * h;   // record slot in the staging area
+            if (r >= 0 && r < kStageTris && s < pending && !(ablate & 4)) {
+                float *dstrec = L->stage + sh + r * kTriDwords;
+#pragma unroll
+                for (int c = 0; c < 18; ++c) dstrec[c] = rec[c];
+                dstrec[18] = __int_as_float(block_id);
+            }
+            VTMC_WAVE_SYNC();
+            // stream coordinates of this round, and the same relative to the staging area (which starts at 608 h)
+            const int lo = h == 0 ? sh : split, hi = (h == 0 && cnt > 32) ? split : end;
+            const int base = 32 * kTriDwords * h;
+            stream_out_range(L->stage - base, gal, lo, hi, lane, ablate);
         }
         VTMC_WAVE_SYNC();
     }

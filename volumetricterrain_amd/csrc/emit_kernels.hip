@@ -15,13 +15,13 @@ namespace vtmc {
 //     parts of the active list through per-part ticket counters, so blocks that share halo rows /
 //     128-byte lines meet in one L2;
 //   * the next block's tile is prefetched into registers while the current one is processed
-//     (16 loads per lane, scalar base + 32-bit lane offsets hoisted out of the block loop);
+//     (20 loads of 5 rows x 10 samples, scalar slab base + two loop-invariant 32-bit lane offsets);
 //   * per-block work: emit_block_from_tile (emit_device.h).
 // ----------------------------------------------------------------------------------------------
 //   INDEXED: welded vertices + block-local indices (emit_block_indexed) instead of 76-byte records;
 //   `out` then is the vertex buffer, voffsets / vcapacity / out_indices its extra operands.
 template <bool FAST, bool INDEXED>
-__global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables tb,
+__global__ __launch_bounds__(256, INDEXED ? 3 : 4) void emit_kernel(BlockSpace sp, DeviceTables tb,
                                                     const uint32_t *__restrict__ offsets,
                                                     const int32_t *__restrict__ active_list,
                                                     const uint32_t *__restrict__ totals, uint32_t capacity,
@@ -48,32 +48,43 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
 
     Lds *L = &s_lds[wave];
 
-    // loop-invariant byte offsets of this lane's 16 tile samples relative to the block origin, and
-    // their LDS destinations (lane index walks the stride-1 axis)
-    unsigned toff[16];
-    int tdst[16];
-    unsigned tyz[16];  // bit positions of the sample's y and z in the 10-bit row-need masks: y | z << 4
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        int idx = it * 64 + lane;
-        idx = idx < 1000 ? idx : 999;
-        const int a = idx % 10, t = idx / 10;
-        const int m = t % 10, c = t / 10;
-        const int ix = sp.zfast ? c : a, iz = sp.zfast ? a : c;
-        toff[it] = (unsigned)(ix * sp.sx + m * sp.sy + iz * sp.sz) * 4u;
-        tdst[it] = ix + 10 * m + 100 * iz;
-        tyz[it] = (unsigned)m | ((unsigned)iz << 4);
-    }
+    // Tile fetch: an instruction covers 5 rows of 10 samples (lane = sample along the stride-1 axis +
+    // 10 * row-in-group; lanes 50-63 idle), 20 instructions cover the 100 rows.  A lane's address is one
+    // of two loop-invariant 32-bit offsets (rows 0-4 / 5-9 of a slab) plus a wave-uniform slab offset, its
+    // LDS destination one index plus an immediate: 3 address registers instead of the 48 a flat
+    // (16 x 64 lanes) enumeration of the 1000 samples needs -- what keeps the kernel at 128 VGPRs.
+    const int lq = lane % 10, rq = lane / 10;          // sample along the fast axis, row within the group
+    const bool lane_ok = rq < 5;
+    const int rqc = lane_ok ? rq : 4;
+    const long long s_fast = sp.zfast ? sp.sz : sp.sx, s_slab = sp.zfast ? sp.sx : sp.sz;
+    const unsigned off0 = (unsigned)(lq * s_fast + rqc * sp.sy) * 4u, off1 = off0 + (unsigned)(5 * sp.sy) * 4u;
+    const unsigned slab_bytes = (unsigned)s_slab * 4u;
+    const int lds0 = sp.zfast ? 100 * lq + 10 * rqc : lq + 10 * rqc;   // tile index of (fast = lq, y = rq, slab 0)
+    const int lds_slab = sp.zfast ? 1 : 100;
     // Row masks from the classify pass (upper half of the block's count word): a tile row (y, z) is only fetched when a cell with triangles
     // can touch it (its layer or one of the two below, on both axes) -- about 64 % of the rows on the
     // benchmark field.  Rows not fetched keep stale values; pass 1 skips their cells.
-    auto load_rows = [&](const char *src, unsigned mask, float (&dst)[16]) {
+    auto load_rows = [&](const char *src, unsigned mask, float (&dst)[20]) {
         const unsigned ym = mask & 0xFFu, zm = mask >> 8;
         const unsigned ny = ym | (ym << 1) | (ym << 2), nz = zm | (zm << 1) | (zm << 2);
+        const bool zl = sp.zfast ? ((nz >> lq) & 1u) != 0u : true;   // z-fastest: the lane's own z row
+        const bool need0 = lane_ok && zl && ((ny >> rqc) & 1u), need1 = lane_ok && zl && ((ny >> (5 + rqc)) & 1u);
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const bool need = ((ny >> (tyz[it] & 15u)) & (nz >> (tyz[it] >> 4)) & 1u) != 0u;
-            if (need && (!(ablate & 8) || it < 10)) dst[it] = *reinterpret_cast<const float *>(src + toff[it]);  // ablate 8: diagnostics
+        for (int c = 0; c < 10; ++c) {
+            if (sp.zfast || ((nz >> c) & 1u)) {   // x-fastest: a whole z slab nobody needs (wave-uniform)
+                const char *p = src + (size_t)c * slab_bytes;
+                if (need0 && (!(ablate & 8) || c < 6)) dst[2 * c] = *reinterpret_cast<const float *>(p + off0);  // ablate 8: diagnostics
+                if (need1 && (!(ablate & 8) || c < 6)) dst[2 * c + 1] = *reinterpret_cast<const float *>(p + off1);
+            }
+        }
+    };
+    auto store_tile = [&](float *tile, const float (&v)[20]) {
+        if (lane_ok) {
+#pragma unroll
+            for (int c = 0; c < 10; ++c) {
+                tile[lds0 + lds_slab * c] = v[2 * c];
+                tile[lds0 + lds_slab * c + 50] = v[2 * c + 1];
+            }
         }
     };
 
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
     };
     auto collect = [&]() { return ai_begin + (int)__builtin_amdgcn_readfirstlane(tick_raw); };
 
-    float pre[16] = {};  // rows a block does not need keep whatever an earlier block left: never used
+    float pre[20] = {};  // rows a block does not need keep whatever an earlier block left: never used
     int b_next = 0;
     unsigned mask_next = 0xFFFFu;
     request();
@@ -127,8 +138,7 @@ __global__ __launch_bounds__(256) void emit_kernel(BlockSpace sp, DeviceTables t
         const size_t tri_base = offsets[b];
         const int budget = (int)(offsets[b + 1] - offsets[b]);  // the scan's count for this block
         VTMC_WAVE_SYNC();
-#pragma unroll
-        for (int it = 0; it < 16; ++it) L->tile[tdst[it]] = pre[it];
+        store_tile(L->tile, pre);
         if (ai_next < ai_end) {  // prefetch the next block's tile; it lands while this one is processed
             b_next = active_list[(ablate & 2) ? ai_begin + (k & 3) : ai_next];
             if (rowmasks) mask_next = rowmasks[b_next] >> 16;
@@ -151,7 +161,7 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
                        const int32_t *active_list, const uint32_t *totals, const uint32_t *counts_or_null, uint32_t capacity,
                        void *triangles, int n_cus, const Tuning &tune, unsigned *queue, hipStream_t stream)
 {
-    int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : 3;  // LDS-limited residency: 3 x 48 KB
+    int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : 4;  // 4 x 40 KB of LDS, 128 VGPRs
     int wgs = n_cus * per_cu;
     wgs = (wgs + 7) & ~7;  // the XCD sweep needs a multiple of 8
     dim3 g(wgs), blk(256);

@@ -53,7 +53,7 @@ struct DeviceTables {
 // A/B knobs (vtmc_set_tuning); defaults are the shipped configuration.
 struct Tuning {
     int emit_fast_math = 1;   // 1: v_rcp/v_rsq (<= ~5e-7 from exact); 0: correctly rounded, bit-compatible with the oracle
-    int emit_wgs_per_cu = 3;
+    int emit_wgs_per_cu = 0;   // 0: the kernel's own residency (4 for the soup, 3 for the indexed output)
     int emit_sub_log2 = 1;    // dynamic mode: 2^s ticket counters per XCD
     int emit_dynamic = 1;     // per-XCD ticket counters instead of a static round-robin over the active list
     int emit_ablate = 0;      // diagnostics only: 1 skip stores, 2 re-read hot tiles, 4 skip vertex math (output invalid)
