@@ -170,7 +170,7 @@ def test_capacity_and_range_errors(ex, oracle_mod):
     assert e.value.code == -6 and "exceed the int32 range" in str(e.value)
     import re
     reported = int(re.search(r"(\d+) triangles", str(e.value)).group(1))
-    assert reported > 2 ** 32
+    assert reported >= 2 ** 32 - 1      # the chained scan saturates its 32-bit triangle words: "at least 2^32 - 1"
     del d
     # the context stays usable
     assert ex.extract_grid(g) == T

@@ -20,11 +20,14 @@ namespace vtmc {
 __global__ __launch_bounds__(256) void classify_blocks_kernel(BlockSpace sp, DeviceTables tb,
                                                                uint32_t *__restrict__ counts,
                                                                uint8_t *__restrict__ cases,
-                                                               uint32_t *__restrict__ vcounts)
+                                                               uint32_t *__restrict__ vcounts,
+                                                               unsigned long long *__restrict__ scan_ctrl, int n_scan_ctrl)
 {
     __shared__ float s_tile[kWavesPerWg][1000];
     __shared__ unsigned char s_trinum[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the fused scan that follows on the stream finds its ticket counter and tile status words zeroed
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_scan_ctrl; i += gridDim.x * 256) scan_ctrl[i] = 0ull;
     s_trinum[threadIdx.x] = tb.tri_num[threadIdx.x];
     __syncthreads();
 
@@ -91,10 +94,13 @@ template <bool WANT_V>
 __global__ __launch_bounds__(256, WANT_V ? 4 : 1) void classify_dense_kernel(BlockSpace sp, DeviceTables tb,
                                                               uint32_t *__restrict__ counts,
                                                               uint32_t *__restrict__ vcounts,
-                                                              int nsegx, int n_bricks, int n_wgs, int ablate)
+                                                              int nsegx, int n_bricks, int n_wgs, int ablate,
+                                                              unsigned long long *__restrict__ scan_ctrl, int n_scan_ctrl)
 {
     __shared__ unsigned char s_trinum[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the fused scan that follows on the stream finds its ticket counter and tile status words zeroed
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_scan_ctrl; i += gridDim.x * 256) scan_ctrl[i] = 0ull;
     s_trinum[threadIdx.x] = tb.tri_num[threadIdx.x];
     __syncthreads();
 
@@ -275,6 +281,130 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restr
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// scan_fused_kernel: the same exclusive scan + compaction in ONE launch (chained scan with decoupled
+// look-back), the default.  A step of the path is then three dispatches -- classify, scan, emit --
+// instead of seven plus two copies; what that buys is fixed cost (~35 us per step), which is what
+// strong scaling over 8 GPUs is short of (a rank's kernels take 0.3 ms there).
+//   * tiles are handed out by a ticket taken when a workgroup STARTS, so every predecessor of a tile
+//     is already running and publishes its aggregate before it waits for anything: no deadlock,
+//     whatever the residency; every spin is bounded all the same (error word -> VTMC_ERR_DEVICE);
+//   * one self-describing 64-bit status word per tile -- state (2 bits: 1 aggregate, 2 inclusive
+//     prefix) | non-empty blocks (30) | triangles (32, saturating) -- written and polled with relaxed
+//     agent-scope atomics: a granule carries its own flag, nothing else needs ordering;
+//   * the words and the ticket counter are zeroed by the classify kernel that precedes the scan on
+//     the stream; this kernel in turn zeroes the emit kernel's ticket queue and writes the totals
+//     straight into the host's pinned words (no copy node).
+// ----------------------------------------------------------------------------------------------
+constexpr unsigned long long kScanAggregate = 1ull << 62, kScanInclusive = 2ull << 62;
+constexpr int kScanSpinLimit = 1 << 22;
+
+__device__ __forceinline__ unsigned long long scan_pack(unsigned long long state, unsigned long long tri, uint32_t act)
+{
+    return state | ((unsigned long long)(act & 0x3FFFFFFFu) << 32) | (tri > 0xFFFFFFFFull ? 0xFFFFFFFFull : tri);
+}
+
+__global__ __launch_bounds__(256) void scan_fused_kernel(const uint32_t *__restrict__ counts, int n, uint32_t *__restrict__ offsets,
+                                                          int32_t *__restrict__ active_list, unsigned long long *__restrict__ ctrl,
+                                                          uint32_t *__restrict__ totals, uint32_t *__restrict__ host_totals,
+                                                          uint32_t *__restrict__ zero_words, int n_zero)
+{
+    __shared__ uint32_t s_w[2][4];
+    __shared__ unsigned s_tile;
+    __shared__ unsigned long long s_ex_tri;
+    __shared__ uint32_t s_ex_act;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned *ticket = reinterpret_cast<unsigned *>(ctrl);   // ctrl[0]: ticket counter, ctrl[1]: error word, ctrl[2 + t]: status of tile t
+    unsigned long long *status = ctrl + 2;
+    if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int t = (int)s_tile, n_tiles = (int)gridDim.x;
+    for (int i = t * 256 + threadIdx.x; i < n_zero; i += n_tiles * 256) zero_words[i] = 0u;   // the emit kernel's ticket queue
+
+    const int base = t * kScanTile + threadIdx.x * 8;
+    uint32_t c[8];
+    uint32_t sum = 0, act = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = base + k;
+        c[k] = i < n ? counts[i] & kCountMask : 0u;
+        sum += c[k];
+        act += c[k] != 0u;
+    }
+    uint32_t is = sum, ia = act, ts, ta;
+    wg_incl_scan2(is, ia, ts, ta, &s_w);   // ts <= 2048 * 2560
+
+    if (wave == 0) {
+        if (lane == 0)
+            __hip_atomic_store(&status[t], scan_pack(t == 0 ? kScanInclusive : kScanAggregate, ts, ta), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long ex_tri = 0;
+        uint32_t ex_act = 0;
+        bool failed = false;
+        for (int j = t - 1; j >= 0; j -= 64) {   // windows of 64 predecessors, nearest first (lane 0 = tile j)
+            const int idx = j - lane;
+            const bool valid = idx >= 0;
+            unsigned long long w = 0;
+            int spins = 0;
+            for (;;) {
+                if (valid) w = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!__builtin_amdgcn_ballot_w64(valid && (w >> 62) == 0ull)) break;
+                if (++spins > kScanSpinLimit) {
+                    failed = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const u64 incl = __builtin_amdgcn_ballot_w64(valid && (w >> 62) == 2ull);
+            const int first = incl ? __builtin_ctzll(incl) : 64;   // nearest tile that already knows its inclusive prefix
+            const bool take = valid && lane <= first;
+            unsigned long long tri = take ? (w & 0xFFFFFFFFull) : 0ull;
+            uint32_t ac = take ? (uint32_t)(w >> 32) & 0x3FFFFFFFu : 0u;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                tri += __shfl_xor(tri, off);
+                ac += __shfl_xor(ac, off);
+            }
+            ex_tri += tri;   // saturating words sum to >= 2^32 - 1 whenever the true sum does
+            ex_act += ac;
+            if (incl || failed) break;
+        }
+        if (lane == 0) {
+            if (t > 0) __hip_atomic_store(&status[t], scan_pack(kScanInclusive, ex_tri + ts, ex_act + ta), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (failed) {
+                reinterpret_cast<unsigned *>(ctrl + 1)[0] = 1u;
+                totals[8] = 1u;
+                if (host_totals) host_totals[8] = 1u;
+            }
+            s_ex_tri = ex_tri;
+            s_ex_act = ex_act;
+        }
+    }
+    __syncthreads();
+    const unsigned long long ex_tri = s_ex_tri;
+    uint32_t off = (uint32_t)ex_tri + is - sum;   // 32-bit offsets: meaningless once T passes 2^32, nothing is emitted then
+    uint32_t aoff = s_ex_act + ia - act;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = base + k;
+        if (i < n) {
+            offsets[i] = off;
+            if (active_list && c[k] != 0u) active_list[aoff++] = i;
+            off += c[k];
+            if (i == n - 1) offsets[n] = off;
+        }
+    }
+    if (t == n_tiles - 1 && threadIdx.x == 0) {
+        unsigned long long T = ex_tri + ts;
+        if (T > 0xFFFFFFFFull) T = 0xFFFFFFFFull;   // saturated somewhere: at least 2^32 - 1
+        const uint32_t tot[4] = {(uint32_t)T, s_ex_act + ta, (uint32_t)T, 0u};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            totals[k] = tot[k];
+            if (host_totals) host_totals[k] = tot[k];
+        }
+    }
+}
+
 // Per-volume {vertices, triangles} -- the array a multi-GPU caller all-gathers.  Soup:
 // 3 unique vertices per triangle (VoxelTerrain.cs:456-459); indexed: the welded vertex count of the
 // volume's blocks, from the second scan.
@@ -294,18 +424,21 @@ __global__ void volume_counts_kernel(const uint32_t *__restrict__ offsets, const
 // launch wrappers
 // ----------------------------------------------------------------------------------------------
 hipError_t launch_classify_blocks(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
-                                  uint8_t *cases_or_null, uint32_t *vcounts_or_null, int n_cus, hipStream_t stream)
+                                  uint8_t *cases_or_null, uint32_t *vcounts_or_null, int n_cus, unsigned long long *scan_ctrl,
+                                  int n_scan_ctrl, hipStream_t stream)
 {
     int wgs = (sp.n_blocks + kWavesPerWg - 1) / kWavesPerWg;
     int cap = n_cus * 8;
     if (wgs > cap) wgs = cap;
     if (wgs < 1) wgs = 1;
-    hipLaunchKernelGGL(classify_blocks_kernel, dim3(wgs), dim3(256), 0, stream, sp, tb, counts, cases_or_null, vcounts_or_null);
+    hipLaunchKernelGGL(classify_blocks_kernel, dim3(wgs), dim3(256), 0, stream, sp, tb, counts, cases_or_null, vcounts_or_null, scan_ctrl,
+                       n_scan_ctrl);
     return hipGetLastError();
 }
 
 hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
-                                 uint32_t *vcounts_or_null, int ablate, hipStream_t stream)
+                                 uint32_t *vcounts_or_null, int ablate, unsigned long long *scan_ctrl, int n_scan_ctrl,
+                                 hipStream_t stream)
 {
     const int nsegx = (sp.nx + 63) / 64;
     const long long n_vol = sp.n_blocks / sp.bpv;
@@ -314,10 +447,10 @@ hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, u
     if (n_wgs > 0x7fffffffll) return hipErrorInvalidValue;
     if (vcounts_or_null)
         hipLaunchKernelGGL((classify_dense_kernel<true>), dim3((unsigned)n_wgs), dim3(256), 0, stream, sp, tb, counts, vcounts_or_null,
-                           nsegx, (int)n_bricks, (int)n_wgs, ablate);
+                           nsegx, (int)n_bricks, (int)n_wgs, ablate, scan_ctrl, n_scan_ctrl);
     else
         hipLaunchKernelGGL((classify_dense_kernel<false>), dim3((unsigned)n_wgs), dim3(256), 0, stream, sp, tb, counts, vcounts_or_null,
-                           nsegx, (int)n_bricks, (int)n_wgs, ablate);
+                           nsegx, (int)n_bricks, (int)n_wgs, ablate, scan_ctrl, n_scan_ctrl);
     return hipGetLastError();
 }
 
@@ -329,6 +462,15 @@ hipError_t launch_scan(const uint32_t *counts, int n_blocks, uint32_t *offsets, 
     hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(256), 0, stream, partials, n_tiles, totals);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, partials, offsets,
                        active_list);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list, unsigned long long *ctrl,
+                             uint32_t *totals, uint32_t *host_totals, uint32_t *zero_words, int n_zero, hipStream_t stream)
+{
+    const int n_tiles = (n_blocks + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(scan_fused_kernel, dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, offsets, active_list, ctrl, totals,
+                       host_totals, zero_words, n_zero);
     return hipGetLastError();
 }
 

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256, INDEXED ? 3 : 4) void emit_kernel(BlockSpace s
                                                     float *__restrict__ out, int group_log2, int ablate, unsigned *__restrict__ queue, int sub_log2,
                                                     const uint32_t *__restrict__ voffsets, const uint32_t *__restrict__ vtotals,
                                                     uint32_t vcapacity, int *__restrict__ out_indices,
-                                                    const uint32_t *__restrict__ rowmasks)
+                                                    const uint32_t *__restrict__ rowmasks, uint32_t *__restrict__ volume_counts, int n_volumes)
 {
     using Lds = typename std::conditional<INDEXED, EmitLdsIdx, EmitLds2>::type;
     __shared__ Lds s_lds[kWavesPerWg];
@@ -41,6 +41,16 @@ __global__ __launch_bounds__(256, INDEXED ? 3 : 4) void emit_kernel(BlockSpace s
 #endif
     __syncthreads();
 
+    // per-volume {vertices, triangles} (the array a multi-GPU caller all-gathers) from the scan's
+    // offsets: a few lanes of the first workgroup instead of a dispatch of its own
+    if (volume_counts && blockIdx.x == 0) {
+        for (int v = threadIdx.x; v < n_volumes; v += 256) {
+            const long long lo = (long long)v * sp.bpv, hi = lo + sp.bpv;
+            const uint32_t t = offsets[hi] - offsets[lo];
+            volume_counts[2 * v] = INDEXED ? voffsets[hi] - voffsets[lo] : 3u * t;   // soup: 3 vertices per triangle (VoxelTerrain.cs:456-459)
+            volume_counts[2 * v + 1] = t;
+        }
+    }
     const uint32_t total_tris = totals[0];
     const int n_active = (int)totals[1];
     if (total_tris > capacity) return;  // host grows the buffer and re-launches (vtmc_api.hip)
@@ -159,7 +169,8 @@ __global__ __launch_bounds__(256, INDEXED ? 3 : 4) void emit_kernel(BlockSpace s
 
 hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets,
                        const int32_t *active_list, const uint32_t *totals, const uint32_t *counts_or_null, uint32_t capacity,
-                       void *triangles, int n_cus, const Tuning &tune, unsigned *queue, hipStream_t stream)
+                       void *triangles, int n_cus, const Tuning &tune, unsigned *queue, uint32_t *volume_counts, int n_volumes,
+                       hipStream_t stream)
 {
     int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : 4;  // 4 x 40 KB of LDS, 128 VGPRs
     int wgs = n_cus * per_cu;
@@ -168,16 +179,16 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
     float *o = (float *)triangles;
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
     if (tune.emit_fast_math)
-        hipLaunchKernelGGL((emit_kernel<true, false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr, tune.emit_row_masks ? counts_or_null : nullptr);
+        hipLaunchKernelGGL((emit_kernel<true, false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes);
     else
-        hipLaunchKernelGGL((emit_kernel<false, false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr, tune.emit_row_masks ? counts_or_null : nullptr);
+        hipLaunchKernelGGL((emit_kernel<false, false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes);
     return hipGetLastError();
 }
 
 hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets, const uint32_t *voffsets,
                                const int32_t *active_list, const uint32_t *totals, const uint32_t *vtotals, uint32_t tri_capacity,
                                uint32_t vert_capacity, void *vertices, void *indices, int n_cus, const Tuning &tune, unsigned *queue,
-                               hipStream_t stream)
+                               uint32_t *volume_counts, int n_volumes, hipStream_t stream)
 {
     int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : 3;
     int wgs = n_cus * per_cu;
@@ -185,9 +196,9 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
     dim3 g(wgs), blk(256);
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
     if (tune.emit_fast_math)
-        hipLaunchKernelGGL((emit_kernel<true, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, nullptr);
+        hipLaunchKernelGGL((emit_kernel<true, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, nullptr, volume_counts, n_volumes);
     else
-        hipLaunchKernelGGL((emit_kernel<false, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, nullptr);
+        hipLaunchKernelGGL((emit_kernel<false, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, nullptr, volume_counts, n_volumes);
     return hipGetLastError();
 }
 

@@ -72,30 +72,36 @@ namespace {
 // One launch of the emit stage on the pending extract's stream, followed by the asynchronous copy of
 // the scan's totals into pinned memory.  The kernel itself refuses to run past its buffers' capacity
 // (it compares the device-resident T / V with the capacities it is handed).
-int queue_emit(vtmc_ctx *ctx)
+int queue_emit(vtmc_ctx *ctx, bool retry)
 {
     const VtmcPending &pe = ctx->pending;
     hipStream_t stream = pe.stream;
     const bool indexed = pe.indexed;
+    const bool fused = ctx->tune.scan_fused != 0;
     const size_t tcap = std::min<size_t>(indexed ? ctx->indices.bytes / (3 * sizeof(int32_t)) : ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
     const size_t vcap = indexed ? std::min<size_t>(ctx->verts.bytes / sizeof(vtmc_vertex), 0x7fffffffu) : 0;
     ctx->pending.tcap = tcap;
     ctx->pending.vcap = vcap;
     uint32_t *queue = (uint32_t *)ctx->totals.p + 64;
-    VTMC_HIP(ctx, hipMemsetAsync(queue, 0, kQueueWords * sizeof(uint32_t), stream));
+    if (!fused || retry)   // the fused scan clears the ticket queue on its way
+        VTMC_HIP(ctx, hipMemsetAsync(queue, 0, kQueueWords * sizeof(uint32_t), stream));
+    uint32_t *vc = fused && pe.n_volumes > 0 ? (uint32_t *)ctx->volcounts.p : nullptr;
     if (indexed)
         VTMC_HIP(ctx, launch_emit_indexed(pe.sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const uint32_t *)ctx->voffsets.p,
                                           (const int32_t *)ctx->active.p, (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->vtotals.p,
-                                          (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p, ctx->indices.p, ctx->n_cus, ctx->tune, queue, stream));
+                                          (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p, ctx->indices.p, ctx->n_cus, ctx->tune, queue, vc,
+                                          pe.n_volumes, stream));
     else
         VTMC_HIP(ctx, launch_emit(pe.sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const int32_t *)ctx->active.p,
                                   (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->counts.p, (uint32_t)tcap, ctx->tris.p,
-                                  ctx->n_cus, ctx->tune, queue, stream));
+                                  ctx->n_cus, ctx->tune, queue, vc, pe.n_volumes, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
-    // {T saturating, nActive, T as 64 bits} -- the scan keeps its running total in 64 bits, so a batch
-    // whose triangle count passes 2^32 is reported as such instead of wrapping to a small count
-    VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->totals.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    if (indexed) VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 4, ctx->vtotals.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (!fused) {
+        // {T saturating, nActive, T as 64 bits} -- the scan keeps its running total in 64 bits, so a batch
+        // whose triangle count passes 2^32 is reported as such instead of wrapping to a small count
+        VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->totals.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (indexed) VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 4, ctx->vtotals.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    }
     return VTMC_OK;
 }
 
@@ -134,7 +140,9 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
         if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * ((size_t)1 << 20))) return rc;
     if (int rc = ensure(ctx, ctx->counts, sizeof(uint32_t) * (size_t)B)) return rc;
     if (int rc = ensure(ctx, ctx->active, sizeof(int32_t) * (size_t)B)) return rc;
-    if (int rc = ensure(ctx, ctx->partials, sizeof(uint32_t) * 2 * (size_t)n_tiles)) return rc;
+    const bool fused = ctx->tune.scan_fused != 0 && B < (1 << 30);   // the status word holds 30 bits of non-empty blocks
+    const size_t ctrl_words = scan_ctrl_words(B);
+    if (int rc = ensure(ctx, ctx->partials, std::max(sizeof(uint32_t) * 2 * (size_t)n_tiles, sizeof(unsigned long long) * 2 * ctrl_words))) return rc;
     if (int rc = ensure(ctx, ctx->totals, sizeof(uint32_t) * (64 + kQueueWords))) return rc;  // scan totals, then the emit kernel's ticket counters
     uint8_t *d_cases = nullptr;
     if (flags & VTMC_FLAG_WANT_CASES) {
@@ -145,7 +153,7 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     if (indexed) {
         if (int rc = ensure(ctx, ctx->vcounts, sizeof(uint32_t) * (size_t)B)) return rc;
         if (int rc = ensure(ctx, ctx->voffsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
-        if (int rc = ensure(ctx, ctx->vpartials, sizeof(uint32_t) * 2 * (size_t)n_tiles)) return rc;
+        if (int rc = ensure(ctx, ctx->vpartials, sizeof(uint32_t) * 2 * (size_t)n_tiles)) return rc;   // three-kernel scan only
         if (int rc = ensure(ctx, ctx->vtotals, sizeof(uint32_t) * 64)) return rc;
         if (!ctx->verts.p)
             if (int rc = ensure(ctx, ctx->verts, sizeof(vtmc_vertex) * ((size_t)1 << 19))) return rc;
@@ -155,22 +163,34 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     }
     const bool dense = !sp.list && sp.sx == 1 && sp.nx >= 32 && !(flags & (VTMC_FLAG_WANT_CASES | VTMC_FLAG_NO_DENSE_PATH));
 
+    unsigned long long *ctrl = fused ? (unsigned long long *)ctx->partials.p : nullptr;
+    const int n_ctrl = fused ? (int)(ctrl_words * (indexed ? 2 : 1)) : 0;
+    if (fused) ctx->h_totals[8] = ctx->h_totals[12] = 0u;   // look-back time-out words of the two scans
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
-    if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_vcounts, ctx->tune.classify_ablate, stream));
-    else VTMC_HIP(ctx, launch_classify_blocks(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_cases, d_vcounts, ctx->n_cus, stream));
+    if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_vcounts, ctx->tune.classify_ablate, ctrl, n_ctrl, stream));
+    else VTMC_HIP(ctx, launch_classify_blocks(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_cases, d_vcounts, ctx->n_cus, ctrl, n_ctrl, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
-    VTMC_HIP(ctx, launch_scan((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p, (int32_t *)ctx->active.p,
-                              (uint32_t *)ctx->partials.p, (uint32_t *)ctx->totals.p, stream));
-    if (indexed)  // the same scan over the welded-vertex counts: per-block vertex offsets + V
-        VTMC_HIP(ctx, launch_scan(d_vcounts, B, (uint32_t *)ctx->voffsets.p, nullptr, (uint32_t *)ctx->vpartials.p,
-                                  (uint32_t *)ctx->vtotals.p, stream));
-    VTMC_HIP(ctx, launch_volume_counts((const uint32_t *)ctx->offsets.p, indexed ? (const uint32_t *)ctx->voffsets.p : nullptr, sp.bpv,
-                                       n_volumes, (uint32_t *)ctx->volcounts.p, stream));
+    if (fused) {
+        // one launch: offsets, active list, totals (also straight into the host's pinned words), emit queue cleared
+        VTMC_HIP(ctx, launch_scan_fused((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p, (int32_t *)ctx->active.p, ctrl,
+                                        (uint32_t *)ctx->totals.p, ctx->h_totals_dev, (uint32_t *)ctx->totals.p + 64, kQueueWords, stream));
+        if (indexed)
+            VTMC_HIP(ctx, launch_scan_fused(d_vcounts, B, (uint32_t *)ctx->voffsets.p, nullptr, ctrl + ctrl_words, (uint32_t *)ctx->vtotals.p,
+                                            ctx->h_totals_dev + 4, nullptr, 0, stream));
+    } else {
+        VTMC_HIP(ctx, launch_scan((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p, (int32_t *)ctx->active.p,
+                                  (uint32_t *)ctx->partials.p, (uint32_t *)ctx->totals.p, stream));
+        if (indexed)  // the same scan over the welded-vertex counts: per-block vertex offsets + V
+            VTMC_HIP(ctx, launch_scan(d_vcounts, B, (uint32_t *)ctx->voffsets.p, nullptr, (uint32_t *)ctx->vpartials.p,
+                                      (uint32_t *)ctx->vtotals.p, stream));
+        VTMC_HIP(ctx, launch_volume_counts((const uint32_t *)ctx->offsets.p, indexed ? (const uint32_t *)ctx->voffsets.p : nullptr, sp.bpv,
+                                           n_volumes, (uint32_t *)ctx->volcounts.p, stream));
+    }
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
     pe.active = true;
     pe.launched = true;
     ctx->pending = pe;
-    return queue_emit(ctx);
+    return queue_emit(ctx, false);
 }
 
 // Completes a queued extract: waits for the stream, reads {T, V} from pinned memory and -- when the
@@ -187,6 +207,10 @@ int extract_finish(vtmc_ctx *ctx, int64_t *tri_count)
     } else {
         for (int attempt = 0;; ++attempt) {
             VTMC_HIP(ctx, hipStreamSynchronize(pe.stream));
+            if (ctx->h_totals[8] || ctx->h_totals[12]) {
+                ctx->pending.active = false;
+                return fail(ctx, VTMC_ERR_DEVICE, "scan: a look-back wait timed out (a predecessor tile never published)");
+            }
             const uint64_t T = ((uint64_t)ctx->h_totals[3] << 32) | ctx->h_totals[2];
             const uint64_t V = pe.indexed ? (((uint64_t)ctx->h_totals[7] << 32) | ctx->h_totals[6]) : 0ull;
             if (T > 0x7fffffffull || V > 0x7fffffffull) {
@@ -208,7 +232,7 @@ int extract_finish(vtmc_ctx *ctx, int64_t *tri_count)
             if ((size_t)V > ctx->pending.vcap)
                 if (int rc = ensure(ctx, ctx->verts, sizeof(vtmc_vertex) * ((size_t)V + (size_t)V / 8 + 1024))) return rc;
             VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], pe.stream));
-            if (int rc = queue_emit(ctx)) return rc;
+            if (int rc = queue_emit(ctx, true)) return rc;
         }
         float a = 0, b = 0, c = 0;
         VTMC_HIP(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
@@ -314,6 +338,8 @@ int32_t vtmc_create(int32_t device, vtmc_ctx **out_ctx)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipHostMalloc((void **)&ctx->h_totals, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
+    memset(ctx->h_totals, 0, 64 * sizeof(uint32_t));
+    if ((e = hipHostGetDevicePointer((void **)&ctx->h_totals_dev, ctx->h_totals, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
 
     // tables: VoxelTerrain.cs:151-156 uploads three int tables; here the packed 2 KB vert table and a
     // 256-byte triangle-count table (the edge-mask table is implied by the vert table)
@@ -557,7 +583,7 @@ int32_t vtmc_read_cases(vtmc_ctx *ctx, uint8_t *dst, int64_t capacity)
     if (int rc = ensure(ctx, ctx->cases, (size_t)need)) return rc;
     DevBuf tmp;
     if (int rc = ensure(ctx, tmp, sizeof(uint32_t) * (size_t)ctx->last_blocks)) return rc;
-    hipError_t e = launch_classify_blocks(ctx->last_space, ctx->tables, (uint32_t *)tmp.p, (uint8_t *)ctx->cases.p, nullptr, ctx->n_cus, ctx->stream);
+    hipError_t e = launch_classify_blocks(ctx->last_space, ctx->tables, (uint32_t *)tmp.p, (uint8_t *)ctx->cases.p, nullptr, ctx->n_cus, nullptr, 0, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(dst, ctx->cases.p, (size_t)need, hipMemcpyDeviceToHost);
     release(tmp);
@@ -671,6 +697,7 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     else if (k == "classify_ablate") ctx->tune.classify_ablate = value;
     else if (k == "emit_row_masks") ctx->tune.emit_row_masks = value;
     else if (k == "density_ablate") ctx->tune.density_ablate = value;
+    else if (k == "scan_fused") ctx->tune.scan_fused = value;
     else if (k == "emit_group_log2") ctx->tune.emit_group_log2 = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (k == "emit_wgs_per_cu") ctx->tune.emit_wgs_per_cu = value;
     else return fail(ctx, VTMC_ERR_INVALID_ARG, "unknown tuning key '%s'", key);

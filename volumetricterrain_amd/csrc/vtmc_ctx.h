@@ -35,6 +35,7 @@ struct vtmc_ctx {
     int output_mode = VTMC_OUTPUT_SOUP;
     bool last_indexed = false;
     int64_t last_verts = 0;
+    uint32_t *h_totals_dev = nullptr;  // the same pinned words as the device sees them (the fused scan writes its totals there)
     uint32_t *h_totals = nullptr;  // pinned: the scan's totals ({T sat, nActive, T lo, T hi}, then the vertex scan's), 64 words
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0..3] stage timing, [4] staging copies
     float stage_ms[4] = {0, 0, 0, 0};

@@ -61,6 +61,7 @@ struct Tuning {
     int emit_row_masks = 1;   // emit loads only the tile rows next to cells with triangles (masks from classify)
     int emit_group_log2 = 0;  // each wave takes 2^g consecutive active-list entries per round
     int density_ablate = 0;   // diagnostics only: 1 the sampler skips its stores (output invalid)
+    int scan_fused = 1;       // 1: one-launch chained scan, volume counts in the emit kernel's prologue, totals written to pinned memory; 0: three scan kernels + copies
 };
 
 // scan scratch layout
@@ -69,22 +70,32 @@ constexpr uint32_t kCountMask = 0xFFFFu;  // counts[b]: triangles (<= 2560) | ro
 constexpr int kScanTile = 2048;  // block counts per scan workgroup (256 threads x 8)
 
 // Launch wrappers (mc_kernels.hip).  All asynchronous on `stream`; return hipGetLastError().
+// scan_ctrl / n_scan_ctrl: 64-bit words the kernel zeroes for the fused scan that follows (may be null / 0)
 hipError_t launch_classify_blocks(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
-                                  uint8_t *cases_or_null, uint32_t *vcounts_or_null, int n_cus, hipStream_t stream);
+                                  uint8_t *cases_or_null, uint32_t *vcounts_or_null, int n_cus, unsigned long long *scan_ctrl,
+                                  int n_scan_ctrl, hipStream_t stream);
 hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
-                                 uint32_t *vcounts_or_null, int ablate, hipStream_t stream);
+                                 uint32_t *vcounts_or_null, int ablate, unsigned long long *scan_ctrl, int n_scan_ctrl,
+                                 hipStream_t stream);
+// one-launch scan: ctrl = 2 + n_tiles words zeroed beforehand (ticket, error, tile status); totals[0..3] = {T saturating, nActive,
+// T, 0}, totals[8] = 1 on a look-back time-out, mirrored into host_totals (device-visible pinned memory) when not null;
+// zero_words / n_zero: 32-bit words to clear on the way (the emit kernel's ticket queue)
+hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list, unsigned long long *ctrl,
+                             uint32_t *totals, uint32_t *host_totals, uint32_t *zero_words, int n_zero, hipStream_t stream);
+inline size_t scan_ctrl_words(int n_blocks) { return 2 + (size_t)((n_blocks + 2047) / 2048); }
 hipError_t launch_scan(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list,
                        uint32_t *partials, uint32_t *totals, hipStream_t stream);
 hipError_t launch_volume_counts(const uint32_t *offsets, const uint32_t *voffsets_or_null, int bpv, int n_volumes,
                                 uint32_t *volume_counts, hipStream_t stream);
 hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets,
                        const int32_t *active_list, const uint32_t *totals, const uint32_t *counts_or_null, uint32_t capacity,
-                       void *triangles, int n_cus, const Tuning &tune, unsigned *queue, hipStream_t stream);
+                       void *triangles, int n_cus, const Tuning &tune, unsigned *queue, uint32_t *volume_counts, int n_volumes,
+                       hipStream_t stream);   // volume_counts != null: the first workgroup also derives the per-volume counts from the offsets
 
 hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets, const uint32_t *voffsets,
                                const int32_t *active_list, const uint32_t *totals, const uint32_t *vtotals, uint32_t tri_capacity,
                                uint32_t vert_capacity, void *vertices, void *indices, int n_cus, const Tuning &tune, unsigned *queue,
-                               hipStream_t stream);
+                               uint32_t *volume_counts, int n_volumes, hipStream_t stream);
 
 // terrain.hip: device-resident density grid with the reference's CSG write semantics.
 struct TerrainShape {
