@@ -1,15 +1,28 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): rocprofv3 kernel stats + the two PMC passes the microarch
-# guide prescribes (FETCH_SIZE and WRITE_SIZE cannot share a pass), all on bench.py itself.
-# usage: tools/profile_round.sh <tag>      -> gpurun_out/prof_<tag>/{stats,fetch,write}
-set -e
-TAG=${1:-r01}
+# Runs on the GPU box (through gpurun): everything a round's profiles/<tag>/ is distilled from
+# (tools/summarize_profiles.py <tag> does the distilling back home).
+#   stats      rocprofv3 --kernel-trace --stats on bench.py itself (the command the driver runs)
+#   fetch/write  the two PMC passes the microarch guide prescribes (FETCH_SIZE and WRITE_SIZE cannot share one)
+#   stream     kernel stats of bench.py --config stream2048
+#   calib      tools/calib/calib: 40-byte-row FETCH_SIZE calibration (with its own PMC pass) + read/write mix ceiling
+#   bench*.json  un-profiled bench lines: N = 1, stream2048, 2 ranks rehearsed on one device; tools/rank_step.py
+# usage: tools/profile_round.sh <tag>      -> gpurun_out/prof_<tag>/
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
-mkdir -p $OUT/stats $OUT/fetch $OUT/write
+mkdir -p $OUT/stats $OUT/fetch $OUT/write $OUT/stream $OUT/calib
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/stats/bench.json 2> $OUT/stats/err.log
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fetch/bench.json 2> $OUT/fetch/err.log
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/write/bench.json 2> $OUT/write/err.log
+T="timeout -k 10 240"
+$T python3 $R/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+$T python3 $R/bench.py --config stream2048 > $OUT/bench_stream2048.json 2> $OUT/bench_stream.err
+VTMC_BENCH_ONE_DEVICE=1 VTMC_BENCH_BACKEND=gloo $T python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29719 $R/bench.py --gpus 2 --steps 20 --warmup 3 > $OUT/bench_2rank_one_device_gloo.json 2> $OUT/bench_2rank.err
+$T python3 $R/tools/rank_step.py 2 4 8 > $OUT/rank_step.txt 2>&1
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/stats/bench.json 2> $OUT/stats/err.log
+$T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fetch/bench.json 2> $OUT/fetch/err.log
+$T rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/write/bench.json 2> $OUT/write/err.log
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stream -- python3 $R/bench.py --config stream2048 --steps 2 --warmup 1 > $OUT/stream/bench.json 2> $OUT/stream/err.log
+$T $R/tools/calib/calib mix > $OUT/calib/mix.json 2> $OUT/calib/err.log
+$T $R/tools/calib/calib rows > $OUT/calib/rows.json 2>> $OUT/calib/err.log
+$T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib/pmc -- $R/tools/calib/calib rows > $OUT/calib/rows_under_pmc.json 2>> $OUT/calib/err.log
 echo "profiles in $OUT"
