@@ -329,7 +329,13 @@ int64_t vto_extract_grid(const float *grid, int64_t sx, int64_t sy, int64_t sz,
  * mode.  The reference has no such format (it welds later with Mesh.Optimize(), VoxelTerrain.cs:460):
  * the welding RULE below is the build's own, everything it evaluates is the reference's arithmetic.
  *   vertex  = one per lattice edge of the block's 9^3 lattice whose endpoints differ in sign class
- *             (CollectTriNum.compute:50, strict '>'), ordered by point x + 9y + 81z, then axis x, y, z;
+ *             (CollectTriNum.compute:50, strict '>').  Every such edge is a cube edge of exactly one
+ *             OWNER cell: the cell whose corner 0 is the edge's low point -- cube edges 0 (x), 3 (y),
+ *             8 (z), MarchingCube.compute:40-43 -- or, where that cell would lie outside the block
+ *             (low point on the x = 8 / y = 8 / z = 8 face), the boundary cell next to it, as its cube
+ *             edge 1, 9 (x = 8), 2, 11 (y = 8), 4, 7 (z = 8), 10, 5, 6 (two faces).  Vertices are ordered
+ *             by owner cell x + 8y + 64z, then by cube edge id: the order falls out of the cells'
+ *             cases (edge mask & ownership mask), so a wave numbers 64 cells with one prefix sum;
  *             position = MarchingCube.compute:128-133 evaluated from the edge's LOW endpoint
  *             (a = low, b = high: t = -cube[a] / (cube[b] - cube[a]), lerp(a, b, t)), normal =
  *             SampleNormalTrilinear (MarchingCube.compute:69-99) at that position;
@@ -361,27 +367,36 @@ int64_t vto_extract_grid_indexed(const float *grid, int64_t sx, int64_t sy, int6
         if (classify_one(tile, flags) == 0) continue;
         normals_one(tile, nrm);
         int32_t nv = 0;
-        for (int z = 0; z < SS; ++z)
-            for (int y = 0; y < SS; ++y)
-                for (int x = 0; x < SS; ++x) {
-                    const int c[3] = {x, y, z};
-                    const int p = x + y * SS + z * SS2, ti = x + y * IS + z * IS2;
-                    for (int a = 0; a < 3; ++a) {
-                        vid[p][a] = -1;
-                        if (c[a] >= BS) continue;
-                        const float va = tile[ti], vb = tile[ti + step[a]];
-                        if ((va > 0) == (vb > 0)) continue;
-                        vid[p][a] = nv;
-                        if (vertices) {
-                            if (V + nv >= vertex_capacity) return -1;
-                            vto_vertex *o = vertices + V + nv;
-                            const float t = (-va) / (vb - va);
-                            for (int k = 0; k < 3; ++k) o->position[k] = lerpf((float)c[k], (float)(c[k] + (k == a)), t);
-                            normal_trilinear(nrm, o->position, o->normal);
-                        }
-                        ++nv;
-                    }
+        for (int p = 0; p < SS3; ++p) vid[p][0] = vid[p][1] = vid[p][2] = -1;
+        for (int cell = 0; cell < 512; ++cell) {
+            const int cc[3] = {cell & 7, (cell >> 3) & 7, cell >> 6};
+            const int mask = g_edge[flags[cell]];   /* cube edges with a sign change, VoxelTerrain.cs:489-507 */
+            for (int e = 0; e < 12 && mask; ++e) {
+                if (!((mask >> e) & 1)) continue;
+                const int a = k_edge_conn[e][0], bb = k_edge_conn[e][1];
+                int lo[3], axis = 0, owned = 1;
+                for (int q = 0; q < 3; ++q) {
+                    const int oa = k_vert_off[a][q], ob = k_vert_off[bb][q];
+                    if (oa != ob) axis = q;
+                    lo[q] = oa < ob ? oa : ob;   /* offset of the edge's low point from the cell's corner 0 */
                 }
+                for (int q = 0; q < 3; ++q)      /* owned: low point at corner 0, or beyond the block on that axis */
+                    if (q != axis && lo[q] == 1 && cc[q] != BS - 1) owned = 0;
+                if (!owned) continue;
+                const int c[3] = {cc[0] + lo[0], cc[1] + lo[1], cc[2] + lo[2]};
+                const int p = c[0] + c[1] * SS + c[2] * SS2, ti = c[0] + c[1] * IS + c[2] * IS2;
+                vid[p][axis] = nv;
+                if (vertices) {
+                    if (V + nv >= vertex_capacity) return -1;
+                    vto_vertex *o = vertices + V + nv;
+                    const float va = tile[ti], vb = tile[ti + step[axis]];
+                    const float t = (-va) / (vb - va);
+                    for (int k = 0; k < 3; ++k) o->position[k] = lerpf((float)c[k], (float)(c[k] + (k == axis)), t);
+                    normal_trilinear(nrm, o->position, o->normal);
+                }
+                ++nv;
+            }
+        }
         for (int cell = 0; cell < 512; ++cell) {
             const int cx = cell & 7, cy = (cell >> 3) & 7, cz = cell >> 6;
             const int flag = (int)flags[cell];

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void classify_blocks_kernel(BlockSpace sp, Dev
 // are served by L2).  No per-cell output: cases are recomputed by the emit kernel from its LDS tile.
 // ----------------------------------------------------------------------------------------------
 template <bool WANT_V>
-__global__ __launch_bounds__(256, WANT_V ? 4 : 1) void classify_dense_kernel(BlockSpace sp, DeviceTables tb,
+__global__ __launch_bounds__(256, WANT_V ? 3 : 1) void classify_dense_kernel(BlockSpace sp, DeviceTables tb,
                                                               uint32_t *__restrict__ counts,
                                                               uint32_t *__restrict__ vcounts,
                                                               int nsegx, int n_bricks, int n_wgs, int ablate,
@@ -304,14 +304,20 @@ __device__ __forceinline__ unsigned long long scan_pack(unsigned long long state
     return state | ((unsigned long long)(act & 0x3FFFFFFFu) << 32) | (tri > 0xFFFFFFFFull ? 0xFFFFFFFFull : tri);
 }
 
+// DUAL: the welded-vertex counts of the indexed output ride along (second count array, second status word
+// per tile, second offsets array): one launch for both scans.
+template <bool DUAL>
 __global__ __launch_bounds__(256) void scan_fused_kernel(const uint32_t *__restrict__ counts, int n, uint32_t *__restrict__ offsets,
                                                           int32_t *__restrict__ active_list, unsigned long long *__restrict__ ctrl,
                                                           uint32_t *__restrict__ totals, uint32_t *__restrict__ host_totals,
-                                                          uint32_t *__restrict__ zero_words, int n_zero)
+                                                          uint32_t *__restrict__ zero_words, int n_zero,
+                                                          const uint32_t *__restrict__ vcounts, uint32_t *__restrict__ voffsets,
+                                                          unsigned long long *__restrict__ vstatus, uint32_t *__restrict__ vtotals)
 {
     __shared__ uint32_t s_w[2][4];
+    __shared__ uint32_t s_v[4];
     __shared__ unsigned s_tile;
-    __shared__ unsigned long long s_ex_tri;
+    __shared__ unsigned long long s_ex_tri, s_ex_vert;
     __shared__ uint32_t s_ex_act;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned *ticket = reinterpret_cast<unsigned *>(ctrl);   // ctrl[0]: ticket counter, ctrl[1]: error word, ctrl[2 + t]: status of tile t
@@ -322,54 +328,93 @@ __global__ __launch_bounds__(256) void scan_fused_kernel(const uint32_t *__restr
     for (int i = t * 256 + threadIdx.x; i < n_zero; i += n_tiles * 256) zero_words[i] = 0u;   // the emit kernel's ticket queue
 
     const int base = t * kScanTile + threadIdx.x * 8;
-    uint32_t c[8];
-    uint32_t sum = 0, act = 0;
+    uint32_t c[8], vc[8];
+    uint32_t sum = 0, act = 0, vsum = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int i = base + k;
         c[k] = i < n ? counts[i] & kCountMask : 0u;
         sum += c[k];
         act += c[k] != 0u;
+        if (DUAL) {
+            vc[k] = i < n ? vcounts[i] : 0u;
+            vsum += vc[k];
+        }
     }
     uint32_t is = sum, ia = act, ts, ta;
     wg_incl_scan2(is, ia, ts, ta, &s_w);   // ts <= 2048 * 2560
+    uint32_t iv = vsum, tv = 0;
+    if (DUAL) {   // a third inclusive scan over the workgroup (<= 2048 * 1944)
+        iv = wave_incl_scan(vsum, lane);
+        if (lane == 63) s_v[wave] = iv;
+        __syncthreads();
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) carry += s_v[w];
+            tv += s_v[w];
+        }
+        iv += carry;
+    }
 
     if (wave == 0) {
-        if (lane == 0)
+        if (lane == 0) {
             __hip_atomic_store(&status[t], scan_pack(t == 0 ? kScanInclusive : kScanAggregate, ts, ta), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long ex_tri = 0;
+            if (DUAL)
+                __hip_atomic_store(&vstatus[t], (t == 0 ? kScanInclusive : kScanAggregate) | (unsigned long long)tv, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned long long ex_tri = 0, ex_vert = 0;
         uint32_t ex_act = 0;
-        bool failed = false;
-        for (int j = t - 1; j >= 0; j -= 64) {   // windows of 64 predecessors, nearest first (lane 0 = tile j)
+        bool failed = false, done_a = false, done_v = !DUAL;
+        for (int j = t - 1; j >= 0 && !(done_a && done_v); j -= 64) {   // windows of 64 predecessors, nearest first (lane 0 = tile j)
             const int idx = j - lane;
             const bool valid = idx >= 0;
-            unsigned long long w = 0;
+            unsigned long long w = 0, wv = kScanInclusive;
             int spins = 0;
             for (;;) {
-                if (valid) w = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!__builtin_amdgcn_ballot_w64(valid && (w >> 62) == 0ull)) break;
+                if (valid) {
+                    w = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (DUAL) wv = __hip_atomic_load(&vstatus[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (!__builtin_amdgcn_ballot_w64(valid && ((w >> 62) == 0ull || (wv >> 62) == 0ull))) break;
                 if (++spins > kScanSpinLimit) {
                     failed = true;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
-            const u64 incl = __builtin_amdgcn_ballot_w64(valid && (w >> 62) == 2ull);
-            const int first = incl ? __builtin_ctzll(incl) : 64;   // nearest tile that already knows its inclusive prefix
-            const bool take = valid && lane <= first;
-            unsigned long long tri = take ? (w & 0xFFFFFFFFull) : 0ull;
-            uint32_t ac = take ? (uint32_t)(w >> 32) & 0x3FFFFFFFu : 0u;
+            if (!done_a) {
+                const u64 incl = __builtin_amdgcn_ballot_w64(valid && (w >> 62) == 2ull);
+                const int first = incl ? __builtin_ctzll(incl) : 64;   // nearest tile that already knows its inclusive prefix
+                const bool take = valid && lane <= first;
+                unsigned long long tri = take ? (w & 0xFFFFFFFFull) : 0ull;
+                uint32_t ac = take ? (uint32_t)(w >> 32) & 0x3FFFFFFFu : 0u;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                tri += __shfl_xor(tri, off);
-                ac += __shfl_xor(ac, off);
+                for (int off = 32; off >= 1; off >>= 1) {
+                    tri += __shfl_xor(tri, off);
+                    ac += __shfl_xor(ac, off);
+                }
+                ex_tri += tri;   // saturating words sum to >= 2^32 - 1 whenever the true sum does
+                ex_act += ac;
+                done_a = incl != 0;
             }
-            ex_tri += tri;   // saturating words sum to >= 2^32 - 1 whenever the true sum does
-            ex_act += ac;
-            if (incl || failed) break;
+            if (DUAL && !done_v) {
+                const u64 incl = __builtin_amdgcn_ballot_w64(valid && (wv >> 62) == 2ull);
+                const int first = incl ? __builtin_ctzll(incl) : 64;
+                unsigned long long vv = (valid && lane <= first) ? (wv & 0x3FFFFFFFFFFFFFFFull) : 0ull;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) vv += __shfl_xor(vv, off);
+                ex_vert += vv;
+                done_v = incl != 0;
+            }
+            if (failed) break;
         }
         if (lane == 0) {
-            if (t > 0) __hip_atomic_store(&status[t], scan_pack(kScanInclusive, ex_tri + ts, ex_act + ta), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t > 0) {
+                __hip_atomic_store(&status[t], scan_pack(kScanInclusive, ex_tri + ts, ex_act + ta), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (DUAL) __hip_atomic_store(&vstatus[t], kScanInclusive | (ex_vert + tv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (failed) {
                 reinterpret_cast<unsigned *>(ctrl + 1)[0] = 1u;
                 totals[8] = 1u;
@@ -377,12 +422,14 @@ __global__ __launch_bounds__(256) void scan_fused_kernel(const uint32_t *__restr
             }
             s_ex_tri = ex_tri;
             s_ex_act = ex_act;
+            s_ex_vert = ex_vert;
         }
     }
     __syncthreads();
     const unsigned long long ex_tri = s_ex_tri;
     uint32_t off = (uint32_t)ex_tri + is - sum;   // 32-bit offsets: meaningless once T passes 2^32, nothing is emitted then
     uint32_t aoff = s_ex_act + ia - act;
+    uint32_t voff = DUAL ? (uint32_t)s_ex_vert + iv - vsum : 0u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int i = base + k;
@@ -391,16 +438,23 @@ __global__ __launch_bounds__(256) void scan_fused_kernel(const uint32_t *__restr
             if (active_list && c[k] != 0u) active_list[aoff++] = i;
             off += c[k];
             if (i == n - 1) offsets[n] = off;
+            if (DUAL) {
+                voffsets[i] = voff;
+                voff += vc[k];
+                if (i == n - 1) voffsets[n] = voff;
+            }
         }
     }
     if (t == n_tiles - 1 && threadIdx.x == 0) {
         unsigned long long T = ex_tri + ts;
         if (T > 0xFFFFFFFFull) T = 0xFFFFFFFFull;   // saturated somewhere: at least 2^32 - 1
-        const uint32_t tot[4] = {(uint32_t)T, s_ex_act + ta, (uint32_t)T, 0u};
+        const unsigned long long V = DUAL ? s_ex_vert + tv : 0ull;
+        const uint32_t tot[8] = {(uint32_t)T, s_ex_act + ta, (uint32_t)T, 0u, V > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)V, 0u, (uint32_t)V, (uint32_t)(V >> 32)};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            totals[k] = tot[k];
-            if (host_totals) host_totals[k] = tot[k];
+        for (int k = 0; k < 8; ++k) {
+            if (k < 4) totals[k] = tot[k];
+            else if (DUAL) vtotals[k - 4] = tot[k];
+            if (host_totals && (k < 4 || DUAL)) host_totals[k] = tot[k];
         }
     }
 }
@@ -466,11 +520,17 @@ hipError_t launch_scan(const uint32_t *counts, int n_blocks, uint32_t *offsets, 
 }
 
 hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list, unsigned long long *ctrl,
-                             uint32_t *totals, uint32_t *host_totals, uint32_t *zero_words, int n_zero, hipStream_t stream)
+                             uint32_t *totals, uint32_t *host_totals, uint32_t *zero_words, int n_zero, const uint32_t *vcounts_or_null,
+                             uint32_t *voffsets, uint32_t *vtotals, hipStream_t stream)
 {
     const int n_tiles = (n_blocks + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL(scan_fused_kernel, dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, offsets, active_list, ctrl, totals,
-                       host_totals, zero_words, n_zero);
+    unsigned long long *vstatus = ctrl + scan_ctrl_words(n_blocks);   // the second half of the control words
+    if (vcounts_or_null)
+        hipLaunchKernelGGL((scan_fused_kernel<true>), dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, offsets, active_list, ctrl, totals,
+                           host_totals, zero_words, n_zero, vcounts_or_null, voffsets, vstatus, vtotals);
+    else
+        hipLaunchKernelGGL((scan_fused_kernel<false>), dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, offsets, active_list, ctrl, totals,
+                           host_totals, zero_words, n_zero, nullptr, nullptr, nullptr, nullptr);
     return hipGetLastError();
 }
 

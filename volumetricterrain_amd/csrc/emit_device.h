@@ -106,16 +106,21 @@ __device__ __forceinline__ void normalise(float d[3])
 // Streams the staged dwords [lo, hi) (stream coordinates: stage[i] goes to gal[i], gal 16-byte aligned)
 // with 16-byte non-temporal stores; the < 4 dwords before the first whole quad and after the last go
 // out as single dwords from lanes 0-3 / 4-7.
+template <int MAX_PASSES = 3>   // 256 dwords per pass: a bound known at compile time keeps the loop's bookkeeping out of the scalar unit
 __device__ __forceinline__ void stream_out_range(const float *stage, float *__restrict__ gal, int lo, int hi, int lane, int ablate)
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const int body_lo = (lo + 3) & ~3, body_hi = hi & ~3;
     if (!(ablate & 1)) {
-        for (int q4 = body_lo + 4 * lane; q4 < body_hi; q4 += 256) {
-            const v4f v = *reinterpret_cast<const v4f *>(stage + q4);
-            v4f *p = reinterpret_cast<v4f *>(gal + q4);
-            if (ablate & 16) __builtin_nontemporal_store(v, p);   // diagnostics: streaming hint (4 % slower at four workgroups per CU)
-            else *p = v;
+#pragma unroll
+        for (int pass = 0; pass < MAX_PASSES; ++pass) {
+            const int q4 = body_lo + 4 * lane + 256 * pass;
+            if (q4 < body_hi) {
+                const v4f v = *reinterpret_cast<const v4f *>(stage + q4);
+                v4f *p = reinterpret_cast<v4f *>(gal + q4);
+                if (ablate & 16) __builtin_nontemporal_store(v, p);   // diagnostics: streaming hint (no faster at four workgroups per CU)
+                else *p = v;
+            }
         }
     }
     const int k = lane & 3;
@@ -206,10 +211,43 @@ __device__ __forceinline__ void emit_flush2(EmitLds2 *L, int pending, size_t tri
             // stream coordinates of this round, and the same relative to the staging area (which starts at 608 h)
             const int lo = h == 0 ? sh : split, hi = (h == 0 && cnt > 32) ? split : end;
             const int base = 32 * kTriDwords * h;
-            stream_out_range(L->stage - base, gal, lo, hi, lane, ablate);
+            stream_out_range<3>(L->stage - base, gal, lo, hi, lane, ablate);
         }
         VTMC_WAVE_SYNC();
     }
+}
+
+// Pass 1 of a block: cases (CollectTriNum.compute:48-51) of the cell layers that can hold triangles and
+// compaction of the active cells, ascending cell id, one ballot per layer.  rowmask bits 0-7 / 8-15: the y /
+// z layers with such cells (0xFFFF = unknown): a dead z layer costs nothing (wave-uniform skip), and the
+// sample plane between two live layers is classified once.  WRITE_CASES also stores every live cell's case.
+template <bool WRITE_CASES>
+__device__ __forceinline__ int compact_active_cells(const float *tile, unsigned short *acell, unsigned char *cases, int lane, unsigned rowmask)
+{
+    const int t0 = (lane & 7) + 10 * (lane >> 3);
+    const bool y_live = (rowmask >> (lane >> 3)) & 1u;
+    int n_act = 0;
+    unsigned lo = 0;
+    bool have_lo = false;
+#pragma unroll
+    for (int z = 0; z < 8; ++z) {
+        if (!((rowmask >> (8 + z)) & 1u)) {   // wave-uniform
+            have_lo = false;
+            continue;
+        }
+        if (!have_lo) lo = layer_nibble(tile, t0, z);
+        const unsigned hi = layer_nibble(tile, t0, z + 1);
+        const unsigned cs = lo | (hi << 4);
+        lo = hi;
+        have_lo = true;
+        const int cell = 64 * z + lane;
+        if (WRITE_CASES) cases[cell] = (unsigned char)cs;
+        const bool act = ((cs + 1u) & 0xFFu) > 1u && y_live;  // neither 0x00 nor 0xFF, in a live y layer
+        const u64 m = __builtin_amdgcn_ballot_w64(act);
+        if (act) acell[n_act + (int)lanes_below(m)] = (unsigned short)cell;
+        n_act += __builtin_popcountll(m);
+    }
+    return n_act;
 }
 
 // Passes 1 + 2 + flush of one block whose 10^3 tile is already in L->tile: cases
@@ -223,23 +261,7 @@ __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_v
                                                      int block_id, float *__restrict__ out, int lane, int ablate,
                                                      unsigned rowmask = 0xFFFFu)
 {
-    const int t0 = (lane & 7) + 10 * (lane >> 3);
-    const bool y_live = (rowmask >> (lane >> 3)) & 1u;
-    // pass 1
-    int n_act = 0;
-    unsigned lo = layer_nibble(L->tile, t0, 0);
-#pragma unroll
-    for (int z = 0; z < 8; ++z) {
-        const unsigned hi = layer_nibble(L->tile, t0, z + 1);
-        const unsigned cs = lo | (hi << 4);
-        lo = hi;
-        const int cell = 64 * z + lane;
-        L->cases[cell] = (unsigned char)cs;
-        const bool act = ((cs + 1u) & 0xFFu) > 1u && y_live && ((rowmask >> (8 + z)) & 1u);  // neither 0x00 nor 0xFF, in a live layer
-        const u64 m = __builtin_amdgcn_ballot_w64(act);
-        if (act) L->acell[n_act + (int)lanes_below(m)] = (unsigned short)cell;
-        n_act += __builtin_popcountll(m);
-    }
+    const int n_act = compact_active_cells<true>(L->tile, L->acell, L->cases, lane, rowmask);   // pass 1
     VTMC_WAVE_SYNC();
 
     // pass 2: triangle slots, 64 active cells per step
@@ -274,82 +296,177 @@ __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_v
 // Indexed (welded) output of one block -- new in the build (the reference welds later, on the CPU,
 // with Mesh.Optimize(), VoxelTerrain.cs:460).  A mesh vertex lives on a lattice edge with a sign
 // change; all cells around that edge share it:
-//   vertices : one 24-byte record {position, normal} per such edge of the block's 9^3 lattice,
-//              ordered by lattice point p = x + 9y + 81z, then axis x, y, z;
+//   vertices : one 24-byte record {position, normal} per such edge of the block's 9^3 lattice.
+//              Every such edge is a cube edge of exactly one OWNER cell -- the cell whose corner 0 is
+//              the edge's low point (cube edges 0, 3, 8 of MarchingCube.compute:40-43), or, on the
+//              block's x = 8 / y = 8 / z = 8 faces, the boundary cell next to it (its edges 1, 9 / 2, 11 /
+//              4, 7 / 10, 5, 6) -- and vertices are ordered by owner cell x + 8y + 64z, then cube edge id.
+//              That order falls out of the ACTIVE cells' cases: owned = edge mask(case) & ownership
+//              mask(cell position), so numbering is one 4-ballot prefix sum per 64 active cells
+//              (round 1 walked the 729 lattice points: twelve steps with four LDS reads each);
 //   indices  : three block-local int32 per triangle, canonical triangle order (as the soup).
 // The vertex is evaluated from the edge's LOW endpoint (the orientation the reference uses for cube
 // edges 0, 1, 4, 5, 8..11); where the reference walks an edge backwards (edges 2, 3, 6, 7) its
 // t' = 1 - t differs from this one by rounding only (<= ~1e-6 in cell units, bar 1e-5).
 // ----------------------------------------------------------------------------------------------
-constexpr int kVertDwords = 6;  // 24-byte vertex record
-constexpr int kVlistCap = 448;  // queued vertices before a flush (a 64-point step adds at most 192)
+constexpr int kVertDwords = 6;   // 24-byte vertex record
+constexpr int kVlistCap = 512;   // vertex descriptors per evaluation window (a block rarely holds more)
+
+// owner-side id of a lattice edge: [axis * 4 + (o_u + 2 o_v)] -> cube edge, (u, v) = the two other axes in order
+constexpr u64 kOwnerEdge = 0x0ull | (2ull << 4) | (4ull << 8) | (6ull << 12) |            // x: (oy, oz)
+                           (3ull << 16) | (1ull << 20) | (7ull << 24) | (5ull << 28) |    // y: (ox, oz)
+                           (8ull << 32) | (9ull << 36) | (11ull << 40) | (10ull << 44);   // z: (ox, oy)
 
 struct __attribute__((aligned(16))) EmitLdsIdx {
     float tile[1000];
-    unsigned slot[kSlotCap];        // triangle slot -> cell | edge triple << 9
+    union {
+        unsigned slot[kSlotCap];          // pass 2: triangle slot -> cell | edge triple << 9
+        unsigned short vlist[kVlistCap];  // vertex phase: vertex id - window -> owner cell | cube edge << 9
+    } q;
     unsigned short acell[512];      // active cells of the block, ascending cell id
-    unsigned char cases[512];
-    unsigned short vmap[736];       // lattice point -> first vertex id | axis flags << 12
-    unsigned short vlist[kVlistCap];  // vertices waiting to be evaluated: point << 2 | axis
-    float stage[64 * kVertDwords + 4];
-};
+    unsigned cellmap[512];          // owner cell -> first vertex id | owned-edge mask << 16 (active cells only)
+    float stage[kStageTris * kVertDwords + 6];
+};   // 9424 bytes: with the two shared tables a workgroup takes 39.9 KB -- four per CU
 static_assert(sizeof(EmitLdsIdx) % 16 == 0 && offsetof(EmitLdsIdx, stage) % 16 == 0, "stage must stay 16-byte aligned");
 
-// streams `n_dw` staged dwords (L->stage + sh ...) to out + d0 with 16-byte stores; sh = d0 & 3
-__device__ __forceinline__ void stream_out_staged(const float *stage, float *__restrict__ out, size_t d0, int sh, int n_dw, int lane)
+// case of cell (cx, cy, cz) from the LDS tile (CollectTriNum.compute:27-51) and its cube edges with a sign
+// change (the reference's cornerToEdgeTable, VoxelTerrain.cs:489-507, as three nibble operations: edges 0-3 /
+// 4-7 are the low / high corner ring xor its rotation, edges 8-11 the two rings xor each other)
+__device__ __forceinline__ unsigned cell_case(const float *tile, unsigned cell)
 {
-    const int lo = sh, hi = sh + n_dw;
-    float *gal = out + (d0 - sh);  // 16-byte aligned
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const int body_lo = (lo + 3) & ~3, body_hi = hi & ~3;
-    for (int q4 = body_lo + 4 * lane; q4 < body_hi; q4 += 256)
-        __builtin_nontemporal_store(*reinterpret_cast<const v4f *>(stage + q4), reinterpret_cast<v4f *>(gal + q4));
-    const int k = lane & 3;
-    const int idx = lane < 4 ? lo + k : body_hi + k;
-    const bool on = lane < 4 ? (idx < body_lo && idx < hi) : (lane < 8 && idx < hi && idx >= body_lo);
-    if (on) __builtin_nontemporal_store(stage[idx], gal + idx);
+    const int t2 = (int)(cell & 7u) + 10 * (int)((cell >> 3) & 7u), cz = (int)(cell >> 6);
+    return layer_nibble(tile, t2, cz) | (layer_nibble(tile, t2, cz + 1) << 4);
+}
+__device__ __forceinline__ unsigned case_edge_mask(unsigned cs)
+{
+    const unsigned n = cs & 15u, m = cs >> 4;
+    const unsigned rn = (n ^ ((n >> 1) | (n << 3))) & 15u, rm = (m ^ ((m >> 1) | (m << 3))) & 15u;
+    return rn | (rm << 4) | ((n ^ m) << 8);
+}
+
+// s_own[e * 8 + b7] for cube edge e of a cell whose coordinates equal 7 where b7 has a bit set: low byte = offset
+// of the OWNER cell's id from the cell's, high byte = the edge's id as the owner sees it (kOwnerEdge)
+__device__ __forceinline__ unsigned short owner_entry(unsigned e, unsigned b7)
+{
+    const unsigned g = (unsigned)(kEdgeGeom >> (5u * e)) & 31u;
+    const unsigned axis = g >> 3, lowoff = g & 7u & ~(1u << axis);   // the low point's offsets on the two other axes
+    const unsigned step = lowoff & ~b7, keep = lowoff & b7;         // into the neighbour cell, unless that leaves the block
+    const unsigned delta = (step & 1u) + 8u * ((step >> 1) & 1u) + 64u * (step >> 2);
+    const unsigned ou = axis == 0 ? (keep >> 1) & 1u : (keep & 1u), ov = axis == 2 ? (keep >> 1) & 1u : (keep >> 2) & 1u;
+    const unsigned eo = (unsigned)(kOwnerEdge >> (4u * (axis * 4u + ou + 2u * ov))) & 15u;
+    return (unsigned short)(delta | (eo << 8));
+}
+
+// cube edges a cell owns: always those at its corner 0; on the block's far faces also the ones beyond
+__device__ __forceinline__ unsigned owned_edges(int cx, int cy, int cz)
+{
+    const unsigned X = cx == 7, Y = cy == 7, Z = cz == 7;
+    return 0x109u | (X * 0x202u) | (Y * 0x804u) | (Z * 0x090u) | ((X & Y) * 0x400u) | ((X & Z) * 0x020u) | ((Y & Z) * 0x040u);
+}
+
+// exclusive wave prefix sum of a per-lane value in 0..15 from four ballots
+__device__ __forceinline__ unsigned wave_prefix4(unsigned n, unsigned &total)
+{
+    u64 m0 = __builtin_amdgcn_ballot_w64((n & 1u) != 0);
+    u64 m1 = __builtin_amdgcn_ballot_w64((n & 2u) != 0);
+    u64 m2 = __builtin_amdgcn_ballot_w64((n & 4u) != 0);
+    u64 m3 = __builtin_amdgcn_ballot_w64((n & 8u) != 0);
+    total = (unsigned)__builtin_popcountll(m0) + 2u * (unsigned)__builtin_popcountll(m1) + 4u * (unsigned)__builtin_popcountll(m2) +
+            8u * (unsigned)__builtin_popcountll(m3);
+    return lanes_below(m0) + 2u * lanes_below(m1) + 4u * lanes_below(m2) + 8u * lanes_below(m3);
+}
+
+// Stages `cnt` records of REC dwords (lane i holds record i) and streams them to out + d0 (dwords).  STAGE_DWORDS
+// is what the staging area holds: when a whole batch fits (the 12-byte index triples) it leaves in one round, else
+// through 33 slots in two rounds split at a 16-byte boundary of the output stream (see emit_flush2).
+template <int REC, int STAGE_DWORDS>
+__device__ __forceinline__ void stream_records(float *stage, const float (&rec)[REC], int cnt, float *__restrict__ out, size_t d0,
+                                               int lane, int ablate)
+{
+    const int sh = (int)(d0 & 3);
+    float *gal = out + (d0 - sh);
+    if (64 * REC + 3 <= STAGE_DWORDS) {
+        VTMC_WAVE_SYNC();
+        if (lane < cnt) {
+            float *d = stage + sh + lane * REC;
+#pragma unroll
+            for (int c = 0; c < REC; ++c) d[c] = rec[c];
+        }
+        VTMC_WAVE_SYNC();
+        stream_out_range<(64 * REC + 3 + 255) / 256>(stage, gal, sh, sh + cnt * REC, lane, ablate);
+        VTMC_WAVE_SYNC();
+        return;
+    }
+    const int split = 32 * REC + (sh ? 4 : 0), end = sh + cnt * REC;
+    for (int h = 0; h == 0 || cnt > 32 * h; ++h) {   // wave-uniform, at most two rounds
+        VTMC_WAVE_SYNC();
+        const int r = lane - 32 * h;
+        if (r >= 0 && r < kStageTris && lane < cnt) {
+            float *d = stage + sh + r * REC;
+#pragma unroll
+            for (int c = 0; c < REC; ++c) d[c] = rec[c];
+        }
+        VTMC_WAVE_SYNC();
+        const int lo = h == 0 ? sh : split, hi = (h == 0 && cnt > 32) ? split : end;
+        stream_out_range<(kStageTris * REC + 3 + 255) / 256>(stage - 32 * REC * h, gal, lo, hi, lane, ablate);
+    }
+    VTMC_WAVE_SYNC();
 }
 
 template <bool FAST>
-__device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_vert, size_t tri_base, int tri_budget,
-                                                   size_t vert_base, int vert_budget, float *__restrict__ out_vertices,
-                                                   int *__restrict__ out_indices, int lane, int ablate = 0)
+__device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_vert, const unsigned short *s_own, size_t tri_base,
+                                                   int tri_budget, size_t vert_base, int vert_budget, float *__restrict__ out_vertices,
+                                                   int *__restrict__ out_indices, int lane, int ablate, unsigned rowmask)
 {
     const float *tile = L->tile;
-    // pass 1: cases + compaction of the active cells (as the soup path)
-    const int t0 = (lane & 7) + 10 * (lane >> 3);
-    int n_act = 0;
-    unsigned lo = layer_nibble(tile, t0, 0);
-#pragma unroll
-    for (int z = 0; z < 8; ++z) {
-        const unsigned hi = layer_nibble(tile, t0, z + 1);
-        const unsigned cs = lo | (hi << 4);
-        lo = hi;
-        const int cell = 64 * z + lane;
-        L->cases[cell] = (unsigned char)cs;
-        const bool act = ((cs + 1u) & 0xFFu) > 1u;
-        const u64 m = __builtin_amdgcn_ballot_w64(act);
-        if (act) L->acell[n_act + (int)lanes_below(m)] = (unsigned short)cell;
-        n_act += __builtin_popcountll(m);
-    }
+    // pass 1: compaction of the active cells (as the soup path, row masks included; cases are re-derived where needed)
+    const int n_act = compact_active_cells<false>(tile, L->acell, nullptr, lane, rowmask);
+    VTMC_WAVE_SYNC();
 
-    // vertices: number the sign-change edges 64 lattice points at a time; their (point, axis) entries
-    // queue up in vlist and are evaluated 64 per step, one lane per vertex
-    int vrun = 0;    // vertices numbered so far
-    int vdone = 0;   // vertices already written out
-    auto flush_vertices = [&]() {
+    // vertex numbering over the active cells, 64 per step: owned sign-change edges -> ids.  Descriptors
+    // of the ids below `window + kVlistCap` are queued on the way (window 0 here; later windows re-walk).
+    auto number_cells = [&](int window, bool write_map) {
+        int vrun = 0;
+        for (int c0 = 0; c0 < n_act; c0 += 64) {
+            const int idx = c0 + lane;
+            const bool valid = idx < n_act;
+            const unsigned cell = valid ? L->acell[idx] : 0u;
+            const int cx = cell & 7, cy = (cell >> 3) & 7, cz = cell >> 6;
+            unsigned owned = valid ? (case_edge_mask(cell_case(tile, cell)) & owned_edges(cx, cy, cz)) : 0u;   // the case again from the tile: cheaper than 512 bytes of LDS
+            unsigned step_total;
+            const unsigned pre = wave_prefix4((unsigned)__builtin_popcount(owned), step_total);
+            int id = vrun + (int)pre;
+            if (valid && write_map) L->cellmap[cell] = (unsigned)id | (owned << 16);
+            while (__builtin_amdgcn_ballot_w64(owned != 0u)) {   // a lane owns 1-3 vertices as a rule, 12 at most
+                if (owned) {
+                    const unsigned e = (unsigned)__builtin_ctz(owned);
+                    const int q = id - window;
+                    if (q >= 0 && q < kVlistCap) L->q.vlist[q] = (unsigned short)(cell | (e << 9));
+                    ++id;
+                    owned &= owned - 1u;
+                }
+            }
+            vrun += (int)step_total;
+        }
+        return vrun;
+    };
+    int n_vert = (ablate & 64) ? 0 : number_cells(0, true);
+    if (n_vert > vert_budget) n_vert = vert_budget;  // never outside the block's slice of the vertex buffer
+
+    // vertex evaluation: one lane per vertex, from the edge's low endpoint
+    for (int window = 0; window < n_vert; window += kVlistCap) {
+        if (window > 0) number_cells(window, false);
         VTMC_WAVE_SYNC();
-        int n_v = (ablate & 16) ? 0 : vrun - vdone;
-        if (vdone + n_v > vert_budget) n_v = vert_budget - vdone > 0 ? vert_budget - vdone : 0;  // never outside the block's slice
-        for (int s0 = 0; s0 < n_v; s0 += 64) {
+        const int n_w = n_vert - window < kVlistCap ? n_vert - window : kVlistCap;
+        for (int s0 = 0; s0 < n_w && !(ablate & 16); s0 += 64) {
             const int s = s0 + lane;
-            const size_t d0 = (vert_base + (size_t)(vdone + s0)) * kVertDwords;
-            const int sh = (int)(d0 & 3);
-            if (s < n_v) {
-                const unsigned ent = L->vlist[s];
-                const unsigned axis = ent & 3u;
-                const int pp = (int)(ent >> 2);
-                const int c[3] = {pp % 9, (pp / 9) % 9, pp / 81};
+            float rec[kVertDwords] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (s < n_w) {
+                const unsigned ent = L->q.vlist[s];
+                const int cell = ent & 511u;
+                const unsigned g = (unsigned)(kEdgeGeom >> (5u * (ent >> 9))) & 31u;
+                const unsigned axis = g >> 3, lowoff = g & 7u & ~(1u << axis);   // endpoint a's offsets, the axis bit cleared: the low point
+                const int c[3] = {(cell & 7) + (int)(lowoff & 1u), ((cell >> 3) & 7) + (int)((lowoff >> 1) & 1u), (cell >> 6) + (int)(lowoff >> 2)};
                 const int sk = axis == 0 ? 1 : (axis == 1 ? 10 : 100);
                 const int tl = c[0] + 10 * c[1] + 100 * c[2];
                 const float va = tile[tl], vb = tile[tl + sk];
@@ -363,74 +480,41 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
                 lattice_gradient(tile, tl + ((int)ceilf(q) - ck) * sk, g1);
                 normalise<FAST>(g0);
                 normalise<FAST>(g1);
-                float *rec = L->stage + sh + lane * kVertDwords;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     rec[a] = axis == (unsigned)a ? q : (float)c[a];
                     rec[3 + a] = FAST ? __builtin_fmaf(w, g1[a] - g0[a], g0[a]) : g0[a] + w * (g1[a] - g0[a]);
                 }
             }
-            VTMC_WAVE_SYNC();
-            const int cnt = n_v - s0 < 64 ? n_v - s0 : 64;
-            stream_out_staged(L->stage, out_vertices, d0, sh, cnt * kVertDwords, lane);
-            VTMC_WAVE_SYNC();
+            const int cnt = n_w - s0 < 64 ? n_w - s0 : 64;
+            stream_records<kVertDwords, kStageTris * kVertDwords + 6>(L->stage, rec, cnt, out_vertices, (vert_base + (size_t)(window + s0)) * kVertDwords, lane, ablate);
         }
-        vdone = vrun;
-    };
-    for (int p0 = 0; p0 < ((ablate & 64) ? 0 : 729); p0 += 64) {
-        if (vrun - vdone > kVlistCap - 192) flush_vertices();  // wave-uniform: the next step may add 192
-        const int p = p0 + lane;
-        unsigned flags = 0;
-        if (p < 729) {
-            const int x = p % 9, y = (p / 9) % 9, z = p / 81;
-            const float *q = tile + x + 10 * y + 100 * z;
-            const bool s0 = q[0] > 0.f;
-            flags = (unsigned)(x < 8 && s0 != (q[1] > 0.f)) | ((unsigned)(y < 8 && s0 != (q[10] > 0.f)) << 1) |
-                    ((unsigned)(z < 8 && s0 != (q[100] > 0.f)) << 2);
-        }
-        unsigned step_total;
-        const unsigned pre = wave_prefix3((unsigned)__builtin_popcount(flags), step_total);
-        if (p < 729) L->vmap[p] = (unsigned short)((unsigned)(vrun + (int)pre) | (flags << 12));
-        unsigned k = (unsigned)(vrun - vdone) + pre;
-#pragma unroll
-        for (unsigned a = 0; a < 3; ++a)
-            if (flags & (1u << a)) L->vlist[k++] = (unsigned short)(((unsigned)p << 2) | a);
-        vrun += (int)step_total;
+        VTMC_WAVE_SYNC();
     }
-    flush_vertices();
 
-    // pass 2 + index flush: triangle slots, 64 active cells per step
+    // pass 2 + index flush: triangle slots, 64 active cells per step; a triangle lane finds each of its
+    // three edges' owner cell and reads the id from the cell map
     auto flush = [&](int pending, size_t base) {
         VTMC_WAVE_SYNC();
         if (ablate & 32) pending = 0;
         for (int s0 = 0; s0 < pending; s0 += 64) {
             const int s = s0 + lane;
-            const size_t d0 = (base + (size_t)s0) * 3;
-            const int sh = (int)(d0 & 3);
+            float rec[3] = {0.f, 0.f, 0.f};
             if (s < pending) {
-                const unsigned sc = L->slot[s];
+                const unsigned sc = L->q.slot[s];
                 const int cell = sc & 511u;
                 const unsigned trip = sc >> 9;
-                const int cx = cell & 7, cy = (cell >> 3) & 7, cz = cell >> 6;
+                const unsigned b7 = (unsigned)((cell & 7) == 7) | ((unsigned)(((cell >> 3) & 7) == 7) << 1) | ((unsigned)((cell >> 6) == 7) << 2);
                 const unsigned e[3] = {trip & 15u, (trip >> 8) & 15u, (trip >> 4) & 15u};  // winding swap, MarchingCube.compute:147-157
-                int *rec = reinterpret_cast<int *>(L->stage) + sh + lane * 3;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const unsigned g = (unsigned)(kEdgeGeom >> (5u * e[k])) & 31u;
-                    const unsigned axis = g >> 3;
-                    int lx = cx + (int)(g & 1u), ly = cy + (int)((g >> 1) & 1u), lz = cz + (int)((g >> 2) & 1u);
-                    // endpoint a on the far end: the lattice edge starts one step back along the axis
-                    lx -= axis == 0 ? (int)(g & 1u) : 0;
-                    ly -= axis == 1 ? (int)((g >> 1) & 1u) : 0;
-                    lz -= axis == 2 ? (int)((g >> 2) & 1u) : 0;
-                    const unsigned vm = L->vmap[lx + 9 * ly + 81 * lz];
-                    rec[k] = (int)((vm & 0xFFFu) + (unsigned)__builtin_popcount((vm >> 12) & ((1u << axis) - 1u)));
+                    const unsigned ow = s_own[e[k] * 8u + b7];                 // owner cell offset | owner-side edge id << 8
+                    const unsigned vm = L->cellmap[cell + (int)(ow & 0xFFu)];
+                    rec[k] = __int_as_float((int)((vm & 0xFFFFu) + (unsigned)__builtin_popcount((vm >> 16) & ((1u << (ow >> 8)) - 1u))));
                 }
             }
-            VTMC_WAVE_SYNC();
             const int cnt = pending - s0 < 64 ? pending - s0 : 64;
-            stream_out_staged(L->stage, reinterpret_cast<float *>(out_indices), d0, sh, cnt * 3, lane);
-            VTMC_WAVE_SYNC();
+            stream_records<3, kStageTris * kVertDwords + 6>(L->stage, rec, cnt, reinterpret_cast<float *>(out_indices), (base + (size_t)s0) * 3, lane, ablate);
         }
     };
     int pending = 0;
@@ -445,11 +529,11 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
         const int idx = c0 + lane;
         const bool valid = idx < n_act;
         const unsigned cell = valid ? L->acell[idx] : 0u;
-        const u64 vw = valid ? s_vert[L->cases[cell]] : 0ull;
+        const u64 vw = valid ? s_vert[cell_case(tile, cell)] : 0ull;
         const unsigned n = (unsigned)(vw >> 60);
         unsigned step_total;
         const unsigned pre_n = wave_prefix3(n, step_total);
-        unsigned *dst = L->slot + pending + pre_n;
+        unsigned *dst = L->q.slot + pending + pre_n;
 #pragma unroll
         for (unsigned i = 0; i < 5; ++i)
             if (i < n) dst[i] = cell | (((unsigned)(vw >> (12 * i)) & 0xFFFu) << 9);

@@ -21,7 +21,7 @@ namespace vtmc {
 //   INDEXED: welded vertices + block-local indices (emit_block_indexed) instead of 76-byte records;
 //   `out` then is the vertex buffer, voffsets / vcapacity / out_indices its extra operands.
 template <bool FAST, bool INDEXED>
-__global__ __launch_bounds__(256, INDEXED ? 3 : 4) void emit_kernel(BlockSpace sp, DeviceTables tb,
+__global__ __launch_bounds__(256, 4) void emit_kernel(BlockSpace sp, DeviceTables tb,
                                                     const uint32_t *__restrict__ offsets,
                                                     const int32_t *__restrict__ active_list,
                                                     const uint32_t *__restrict__ totals, uint32_t capacity,
@@ -33,9 +33,11 @@ __global__ __launch_bounds__(256, INDEXED ? 3 : 4) void emit_kernel(BlockSpace s
     using Lds = typename std::conditional<INDEXED, EmitLdsIdx, EmitLds2>::type;
     __shared__ Lds s_lds[kWavesPerWg];
     __shared__ u64 s_vert[256];
+    __shared__ unsigned short s_own[INDEXED ? 96 : 1];   // (cube edge, which coordinates are 7) -> owner cell offset | owner-side edge id
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     s_vert[threadIdx.x] = tb.vert_packed[threadIdx.x];
+    if (INDEXED && threadIdx.x < 96) s_own[threadIdx.x] = owner_entry(threadIdx.x >> 3, threadIdx.x & 7u);
 #ifdef VTMC_DEBUG_POISON_LDS  // diagnostic build: NaN-fill LDS so any read of a never-written word shows up in the output
     for (unsigned i = threadIdx.x; i < sizeof(s_lds) / 4; i += 256) reinterpret_cast<unsigned *>(s_lds)[i] = 0x7FC00000u;
 #endif
@@ -79,13 +81,19 @@ __global__ __launch_bounds__(256, INDEXED ? 3 : 4) void emit_kernel(BlockSpace s
         const unsigned ny = ym | (ym << 1) | (ym << 2), nz = zm | (zm << 1) | (zm << 2);
         const bool zl = sp.zfast ? ((nz >> lq) & 1u) != 0u : true;   // z-fastest: the lane's own z row
         const bool need0 = lane_ok && zl && ((ny >> rqc) & 1u), need1 = lane_ok && zl && ((ny >> (5 + rqc)) & 1u);
+        // the two row groups under ONE exec mask each (a lane's need is the same for all ten slabs), slab pointer
+        // advanced by addition: the scalar unit sees two mask set-ups and ten adds per tile, not twenty of each
+        if (need0) {
+            const char *p = src + off0;
 #pragma unroll
-        for (int c = 0; c < 10; ++c) {
-            if (sp.zfast || ((nz >> c) & 1u)) {   // x-fastest: a whole z slab nobody needs (wave-uniform)
-                const char *p = src + (size_t)c * slab_bytes;
-                if (need0 && (!(ablate & 8) || c < 6)) dst[2 * c] = *reinterpret_cast<const float *>(p + off0);  // ablate 8: diagnostics
-                if (need1 && (!(ablate & 8) || c < 6)) dst[2 * c + 1] = *reinterpret_cast<const float *>(p + off1);
-            }
+            for (int c = 0; c < 10; ++c, p += slab_bytes)
+                if ((sp.zfast || ((nz >> c) & 1u)) && (!(ablate & 8) || c < 6)) dst[2 * c] = *reinterpret_cast<const float *>(p);   // x-fastest: a z slab nobody needs is skipped (wave-uniform); ablate 8: diagnostics
+        }
+        if (need1) {
+            const char *p = src + off1;
+#pragma unroll
+            for (int c = 0; c < 10; ++c, p += slab_bytes)
+                if ((sp.zfast || ((nz >> c) & 1u)) && (!(ablate & 8) || c < 6)) dst[2 * c + 1] = *reinterpret_cast<const float *>(p);
         }
     };
     auto store_tile = [&](float *tile, const float (&v)[20]) {
@@ -158,8 +166,8 @@ __global__ __launch_bounds__(256, INDEXED ? 3 : 4) void emit_kernel(BlockSpace s
         VTMC_WAVE_SYNC();
 
         if constexpr (INDEXED)
-            emit_block_indexed<FAST>(L, s_vert, tri_base, budget, (size_t)voffsets[b], (int)(voffsets[b + 1] - voffsets[b]), out,
-                                     out_indices, lane, ablate);
+            emit_block_indexed<FAST>(L, s_vert, s_own, tri_base, budget, (size_t)voffsets[b], (int)(voffsets[b + 1] - voffsets[b]), out,
+                                     out_indices, lane, ablate, mask);
         else
             emit_block_from_tile<FAST>(L, s_vert, tri_base, budget, b, out, lane, ablate, mask);
         ai = ai_next;
@@ -186,19 +194,20 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
 }
 
 hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets, const uint32_t *voffsets,
-                               const int32_t *active_list, const uint32_t *totals, const uint32_t *vtotals, uint32_t tri_capacity,
+                               const int32_t *active_list, const uint32_t *totals, const uint32_t *vtotals, const uint32_t *counts_or_null,
+                               uint32_t tri_capacity,
                                uint32_t vert_capacity, void *vertices, void *indices, int n_cus, const Tuning &tune, unsigned *queue,
                                uint32_t *volume_counts, int n_volumes, hipStream_t stream)
 {
-    int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : 3;
+    int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : 4;   // 39.9 KB of LDS, <= 128 VGPRs
     int wgs = n_cus * per_cu;
     wgs = (wgs + 7) & ~7;
     dim3 g(wgs), blk(256);
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
     if (tune.emit_fast_math)
-        hipLaunchKernelGGL((emit_kernel<true, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, nullptr, volume_counts, n_volumes);
+        hipLaunchKernelGGL((emit_kernel<true, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes);
     else
-        hipLaunchKernelGGL((emit_kernel<false, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, nullptr, volume_counts, n_volumes);
+        hipLaunchKernelGGL((emit_kernel<false, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes);
     return hipGetLastError();
 }
 

@@ -155,44 +155,41 @@ __device__ __forceinline__ unsigned classify_brick_column(const BlockSpace &sp, 
         and_all &= A[zz] & N[zz];
     }
 
-    unsigned total = 0, rows = 0, yacc = 0;
+    unsigned total = 0, rows = 0, yacc = 0, vtotal = 0;
     const bool uniform = (or_all == 0u) || (and_all == 0x1FFu);
-    if (WANT_V) {
-        unsigned v = 0;
-        if (!uniform) {
-            const bool far_plane = (lane & 7) == 7;
-#pragma unroll
-            for (int zz = 0; zz < 9; ++zz) {
-                v += __builtin_popcount((A[zz] ^ N[zz]) & 0x1FFu);            // x-edges
-                v += __builtin_popcount((A[zz] ^ (A[zz] >> 1)) & 0xFFu);      // y-edges
-                if (zz < 8) v += __builtin_popcount((A[zz] ^ A[zz + 1]) & 0x1FFu);  // z-edges
-                if (far_plane) {
-                    v += __builtin_popcount((N[zz] ^ (N[zz] >> 1)) & 0xFFu);
-                    if (zz < 8) v += __builtin_popcount((N[zz] ^ N[zz + 1]) & 0x1FFu);
-                }
-            }
-        }
-        *vcount = gx >= sp.nx ? 0u : v;
-    }
     if (__builtin_amdgcn_ballot_w64(!uniform) != 0) {
         // NIB[zz] nibble yy = corners (0,1,2,3) of the cell column at sample layer zz
+        // built bit-parallel: the 8 + 1 sign bits of a column are spread to every 4th bit (three shift-or-mask
+        // steps), the neighbours' follow by a shift -- 21 VALU per plane instead of 8 per cell
         unsigned NIB[9];
+        auto spread4 = [](unsigned x) {   // bit i (i < 8) -> bit 4 i
+            x = (x | (x << 12)) & 0x000F000Fu;
+            x = (x | (x << 6)) & 0x03030303u;
+            return (x | (x << 3)) & 0x11111111u;
+        };
 #pragma unroll
         for (int zz = 0; zz < 9; ++zz) {
-            unsigned w = 0;
-#pragma unroll
-            for (int yy = 0; yy < 8; ++yy) {
-                unsigned a2 = (A[zz] >> yy) & 3u, n2 = (N[zz] >> yy) & 3u;
-                unsigned nib = (a2 & 1u) | (n2 << 1) | ((a2 & 2u) << 2);
-                w |= nib << (4 * yy);
-            }
-            NIB[zz] = w;
+            const unsigned a0 = spread4(A[zz] & 0xFFu), n0 = spread4(N[zz] & 0xFFu);
+            const unsigned a1 = (a0 >> 4) | ((A[zz] & 0x100u) << 20), n1 = (n0 >> 4) | ((N[zz] & 0x100u) << 20);   // rows y + 1
+            NIB[zz] = a0 | (n0 << 1) | (n1 << 2) | (a1 << 3);   // corners 0 (x,y), 1 (x+1,y), 2 (x+1,y+1), 3 (x,y+1)
         }
 #pragma unroll
         for (int zz = 0; zz < 8; ++zz) {
             const unsigned lo = NIB[zz], hi = NIB[zz + 1];
             const bool flat = ((lo | hi) == 0u) || ((lo & hi) == 0xFFFFFFFFu);
             if (__builtin_amdgcn_ballot_w64(!flat) == 0) continue;
+            if (WANT_V) {   // lattice edges with a sign change in sample plane zz (x-, y-edges), between planes zz and zz + 1
+                            // (z-edges) and, from the last layer, in plane 8: a layer skipped above holds none of them
+                const bool far_plane = (lane & 7) == 7;
+                vtotal += __builtin_popcount((A[zz] ^ N[zz]) & 0x1FFu) + __builtin_popcount((A[zz] ^ (A[zz] >> 1)) & 0xFFu) +
+                          __builtin_popcount((A[zz] ^ A[zz + 1]) & 0x1FFu);
+                if (far_plane)
+                    vtotal += __builtin_popcount((N[zz] ^ (N[zz] >> 1)) & 0xFFu) + __builtin_popcount((N[zz] ^ N[zz + 1]) & 0x1FFu);
+                if (zz == 7) {
+                    vtotal += __builtin_popcount((A[8] ^ N[8]) & 0x1FFu) + __builtin_popcount((A[8] ^ (A[8] >> 1)) & 0xFFu);
+                    if (far_plane) vtotal += __builtin_popcount((N[8] ^ (N[8] >> 1)) & 0xFFu);
+                }
+            }
             if (!(ablate & 8)) {   // cells of this layer with a mixed case (= with triangles), one bit per nibble: not all 0, not all 1
                 const unsigned any = lo | hi, all = lo & hi;
                 const unsigned nz = (any | (any >> 1) | (any >> 2) | (any >> 3)) & 0x11111111u;
@@ -214,8 +211,9 @@ __device__ __forceinline__ unsigned classify_brick_column(const BlockSpace &sp, 
             x = (x | (x >> 12)) & 0xFFu;
             rows |= x;
         }
-        if (gx >= sp.nx) total = 0, rows = 0;  // lanes past the last cell of a partial segment
+        if (gx >= sp.nx) total = 0, rows = 0, vtotal = 0;  // lanes past the last cell of a partial segment
     }
+    if (WANT_V) *vcount = vtotal;
     if (rowmask) *rowmask = rows;
     return total;
 }

@@ -89,7 +89,7 @@ int queue_emit(vtmc_ctx *ctx, bool retry)
     if (indexed)
         VTMC_HIP(ctx, launch_emit_indexed(pe.sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const uint32_t *)ctx->voffsets.p,
                                           (const int32_t *)ctx->active.p, (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->vtotals.p,
-                                          (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p, ctx->indices.p, ctx->n_cus, ctx->tune, queue, vc,
+                                          (const uint32_t *)ctx->counts.p, (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p, ctx->indices.p, ctx->n_cus, ctx->tune, queue, vc,
                                           pe.n_volumes, stream));
     else
         VTMC_HIP(ctx, launch_emit(pe.sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const int32_t *)ctx->active.p,
@@ -165,7 +165,7 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
 
     unsigned long long *ctrl = fused ? (unsigned long long *)ctx->partials.p : nullptr;
     const int n_ctrl = fused ? (int)(ctrl_words * (indexed ? 2 : 1)) : 0;
-    if (fused) ctx->h_totals[8] = ctx->h_totals[12] = 0u;   // look-back time-out words of the two scans
+    if (fused) ctx->h_totals[8] = 0u;   // the scan's look-back time-out word
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
     if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_vcounts, ctx->tune.classify_ablate, ctrl, n_ctrl, stream));
     else VTMC_HIP(ctx, launch_classify_blocks(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_cases, d_vcounts, ctx->n_cus, ctrl, n_ctrl, stream));
@@ -173,10 +173,8 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     if (fused) {
         // one launch: offsets, active list, totals (also straight into the host's pinned words), emit queue cleared
         VTMC_HIP(ctx, launch_scan_fused((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p, (int32_t *)ctx->active.p, ctrl,
-                                        (uint32_t *)ctx->totals.p, ctx->h_totals_dev, (uint32_t *)ctx->totals.p + 64, kQueueWords, stream));
-        if (indexed)
-            VTMC_HIP(ctx, launch_scan_fused(d_vcounts, B, (uint32_t *)ctx->voffsets.p, nullptr, ctrl + ctrl_words, (uint32_t *)ctx->vtotals.p,
-                                            ctx->h_totals_dev + 4, nullptr, 0, stream));
+                                        (uint32_t *)ctx->totals.p, ctx->h_totals_dev, (uint32_t *)ctx->totals.p + 64, kQueueWords, d_vcounts,
+                                        indexed ? (uint32_t *)ctx->voffsets.p : nullptr, indexed ? (uint32_t *)ctx->vtotals.p : nullptr, stream));
     } else {
         VTMC_HIP(ctx, launch_scan((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p, (int32_t *)ctx->active.p,
                                   (uint32_t *)ctx->partials.p, (uint32_t *)ctx->totals.p, stream));
@@ -207,7 +205,7 @@ int extract_finish(vtmc_ctx *ctx, int64_t *tri_count)
     } else {
         for (int attempt = 0;; ++attempt) {
             VTMC_HIP(ctx, hipStreamSynchronize(pe.stream));
-            if (ctx->h_totals[8] || ctx->h_totals[12]) {
+            if (ctx->h_totals[8]) {
                 ctx->pending.active = false;
                 return fail(ctx, VTMC_ERR_DEVICE, "scan: a look-back wait timed out (a predecessor tile never published)");
             }

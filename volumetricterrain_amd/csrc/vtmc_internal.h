@@ -80,8 +80,11 @@ hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, u
 // one-launch scan: ctrl = 2 + n_tiles words zeroed beforehand (ticket, error, tile status); totals[0..3] = {T saturating, nActive,
 // T, 0}, totals[8] = 1 on a look-back time-out, mirrored into host_totals (device-visible pinned memory) when not null;
 // zero_words / n_zero: 32-bit words to clear on the way (the emit kernel's ticket queue)
+// vcounts_or_null != null: the welded-vertex counts are scanned in the same launch (voffsets, vtotals[0..3] = {V saturating, 0, V lo, V hi},
+// host_totals[4..7]); ctrl then holds 2 * scan_ctrl_words(n_blocks) zeroed words
 hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list, unsigned long long *ctrl,
-                             uint32_t *totals, uint32_t *host_totals, uint32_t *zero_words, int n_zero, hipStream_t stream);
+                             uint32_t *totals, uint32_t *host_totals, uint32_t *zero_words, int n_zero, const uint32_t *vcounts_or_null,
+                             uint32_t *voffsets, uint32_t *vtotals, hipStream_t stream);
 inline size_t scan_ctrl_words(int n_blocks) { return 2 + (size_t)((n_blocks + 2047) / 2048); }
 hipError_t launch_scan(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list,
                        uint32_t *partials, uint32_t *totals, hipStream_t stream);
@@ -93,7 +96,8 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
                        hipStream_t stream);   // volume_counts != null: the first workgroup also derives the per-volume counts from the offsets
 
 hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets, const uint32_t *voffsets,
-                               const int32_t *active_list, const uint32_t *totals, const uint32_t *vtotals, uint32_t tri_capacity,
+                               const int32_t *active_list, const uint32_t *totals, const uint32_t *vtotals, const uint32_t *counts_or_null,
+                               uint32_t tri_capacity,
                                uint32_t vert_capacity, void *vertices, void *indices, int n_cus, const Tuning &tune, unsigned *queue,
                                uint32_t *volume_counts, int n_volumes, hipStream_t stream);
 
