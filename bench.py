@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--cpu-sample-chunks", type=int, default=32, help="chunks the CPU oracle is timed on")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0: physical cores in this process's CPU share, at most 16 per GPU)")
     ap.add_argument("--no-dense", action="store_true", help="A/B: force the per-block classify kernel")
+    ap.add_argument("--no-indexed", action="store_true", help="skip the extra indexed-output steps at N = 1")
     args = ap.parse_args()
     if args.config == "stream2048":
         args.n = args.n or 2048
@@ -349,6 +350,35 @@ def run_grid(args, torch, dist):
                 "achieved_GBps": round(path_bytes / (avg["total"] * 1e-3) / 1e9, 1),
                 "frac_of_peak": round(path_bytes / (avg["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "read_only_frac_of_peak": round(4.0 * samples / (avg["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # the same workload in the welded (indexed) output format -- 24 B per vertex + 12 B per triangle instead of 76 B
+        # per triangle: a few steps after the timed region, N = 1 only (not part of `value`)
+        indexed = None
+        if world == 1 and not args.no_indexed:
+            ex.set_output_mode(True)
+            try:
+                for _ in range(2):
+                    ex.extract_volumes_device(d_field.data_ptr(), (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, stream.cuda_stream, flags)
+                acc = {"classify": 0.0, "scan": 0.0, "emit": 0.0, "total": 0.0}
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                K = max(3, args.steps // 2)
+                for _ in range(K):
+                    Ti = ex.extract_volumes_device(d_field.data_ptr(), (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, stream.cuda_stream, flags)
+                    for k, v in ex.last_stage_ms().items():
+                        acc[k] += v / K
+                torch.cuda.synchronize()
+                ms_i = (time.perf_counter() - t0) / K * 1e3
+                V = ex.last_vertex_count()
+                ibytes = 4.0 * samples + 24.0 * V + 12.0 * Ti + 8.0 * n_chunks
+                indexed = {"ms_per_step": round(ms_i, 4), "mvoxels_per_s": round(cells_total / (ms_i * 1e-3) / 1e6, 1),
+                           "vertices": int(V), "triangles": int(Ti), "output_bytes": 24.0 * V + 12.0 * Ti,
+                           "output_bytes_vs_soup": round((24.0 * V + 12.0 * Ti) / (76.0 * Ti), 4),
+                           "kernels_ms": {k: round(v, 4) for k, v in acc.items()},
+                           "path_roofline": {"bytes": ibytes, "achieved_GBps": round(ibytes / (acc["total"] * 1e-3) / 1e9, 1),
+                                             "frac_of_peak": round(ibytes / (acc["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                           "speedup_over_soup_step": round(ms_per_step / ms_i, 3)}
+            finally:
+                ex.set_output_mode(False)
         cpu = None
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             k = min(args.cpu_sample_chunks, n_chunks)
@@ -388,6 +418,7 @@ def run_grid(args, torch, dist):
             "allgather_ms": None if world == 1 else {"avg": round(statistics.mean(gather_ms), 4), "max": round(max(gather_ms), 4),
                                                      "note": "HIP events around the collective on the extract's stream, rank 0"},
             "host_ms_per_step_beyond_kernels": round(ms_per_step - avg["total"], 4),
+            "indexed_output": indexed,
             "cpu_baseline": cpu,
             "sampler_s": round(sampler_s, 4),
             "sampler_kernel_ms": round(sampler_kernel_ms, 3),

@@ -35,6 +35,8 @@ def test_single_gpu_line_carries_roofline_and_reproducible_cpu_leg():
     assert all(s >= 0.5 for s in c["repetition_seconds"])
     assert c["min_mvoxels_per_s"] <= c["value"] <= c["max_mvoxels_per_s"]
     assert c["cpu_share"]["affinity_cpus"] >= c["cores"]
+    ix = j["indexed_output"]
+    assert ix["triangles"] == j["triangles_total"] and 0 < ix["output_bytes_vs_soup"] < 0.45 and ix["ms_per_step"] > 0
     # 256^3 perlin3d as 8 chunks of 128^3: the surface of the one-grid config (2 655 156 triangles with the CPU
     # twin's samples; the device sampler differs from the twin by ~1e-7, which moves the samples that are
     # zero in exact arithmetic -- the noise lattice points -- across the threshold: a few hundred triangles)

@@ -52,6 +52,16 @@ def main():
     json.dump({"FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB": write,
                "note": "last dispatch of each kernel in a bench.py run; FETCH_SIZE raw = TCC_EA0_RDREQ x 64 B"},
               open(os.path.join(dst, "pmc_fetch_write.json"), "w"), indent=1)
+    ist = first(os.path.join(src, "indexed", "*", "*_kernel_stats.csv"))
+    if ist:
+        shutil.copy(ist, os.path.join(dst, "kernel_stats_indexed.csv"))
+        try:
+            fi = last_per_kernel(first(os.path.join(src, "indexed_fetch", "*", "*_counter_collection.csv")), "FETCH_SIZE")
+            wi = last_per_kernel(first(os.path.join(src, "indexed_write", "*", "*_counter_collection.csv")), "WRITE_SIZE")
+            json.dump({"FETCH_SIZE_KiB_raw": fi, "WRITE_SIZE_KiB": wi, "note": "tools/ab_bench.py indexed=1: the <true, true> emit kernel and the <true> classify kernel are the indexed pipeline's"},
+                      open(os.path.join(dst, "pmc_fetch_write_indexed.json"), "w"), indent=1)
+        except Exception as e:   # noqa: BLE001
+            print("no indexed pmc:", e)
     calib = {}
     try:
         rows = json.load(open(os.path.join(src, "calib", "rows.json")))

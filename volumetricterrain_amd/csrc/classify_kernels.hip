@@ -153,9 +153,7 @@ __global__ __launch_bounds__(256, WANT_V ? 3 : 1) void classify_dense_kernel(Blo
 // A count word holds the triangle count in its low 16 bits (kCountMask) and the block's row mask above.
 // Replaces the single-address InterlockedAdd (CollectTriNum.compute:54), the 4-byte read-back
 // (VoxelTerrain.cs:394-395) and the append cursor (MarchingCube.compute:160-162).
-//   reduce : per 2048-block tile {triangles, non-empty blocks}
-//   spine  : one workgroup scans the tile sums, publishes totals = {T, nActive}
-//   apply  : per-block exclusive offsets, active list, per-volume {vertices, triangles}
+//   one launch (scan_fused_kernel): per-block exclusive offsets, active list, totals = {T, nActive}
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 {
@@ -197,93 +195,8 @@ __device__ __forceinline__ void wg_incl_scan2(uint32_t &a, uint32_t &b, uint32_t
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void scan_reduce_kernel(const uint32_t *__restrict__ counts, int n,
-                                                           uint32_t *__restrict__ partials)
-{
-    __shared__ uint32_t s_w[2][4];
-    const int base = blockIdx.x * kScanTile + threadIdx.x * 8;
-    uint32_t sum = 0, act = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        int i = base + k;
-        uint32_t c = i < n ? counts[i] & kCountMask : 0u;
-        sum += c;
-        act += c != 0u;
-    }
-    uint32_t ts, ta;
-    wg_incl_scan2(sum, act, ts, ta, &s_w);
-    if (threadIdx.x == 0) {
-        partials[2 * blockIdx.x] = ts;
-        partials[2 * blockIdx.x + 1] = ta;
-    }
-}
-
-// The running total is kept in 64 bits: a batch may hold up to 2^31-1 blocks of up to 2560 triangles,
-// so T can pass 2^32 and a 32-bit carry would wrap to a small, plausible-looking count.  totals[0]
-// saturates at 0xFFFFFFFF in that case (the host turns any T > 2^31-1 into VTMC_ERR_TOO_LARGE, the
-// emit kernel refuses to run because no capacity reaches it); totals[2..3] hold the exact 64-bit T.
-__global__ __launch_bounds__(256) void scan_spine_kernel(uint32_t *__restrict__ partials, int n_tiles,
-                                                          uint32_t *__restrict__ totals)
-{
-    __shared__ uint32_t s_w[2][4];
-    unsigned long long carry_s = 0;
-    uint32_t carry_a = 0;
-    for (int start = 0; start < n_tiles; start += 256) {
-        int i = start + threadIdx.x;
-        uint32_t s = i < n_tiles ? partials[2 * i] : 0u;   // <= 2048 * 2560 per tile: 256 of them fit 32 bits
-        uint32_t a = i < n_tiles ? partials[2 * i + 1] : 0u;
-        uint32_t is = s, ia = a, ts, ta;
-        wg_incl_scan2(is, ia, ts, ta, &s_w);
-        if (i < n_tiles) {
-            partials[2 * i] = (uint32_t)carry_s + is - s;  // exclusive (meaningless once T overflows: nothing is emitted then)
-            partials[2 * i + 1] = carry_a + ia - a;
-        }
-        carry_s += ts;
-        carry_a += ta;
-    }
-    if (threadIdx.x == 0) {
-        totals[0] = carry_s > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)carry_s;  // T, saturating
-        totals[1] = carry_a;                                                     // number of non-empty blocks
-        totals[2] = (uint32_t)carry_s;
-        totals[3] = (uint32_t)(carry_s >> 32);
-    }
-}
-
-__global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restrict__ counts, int n,
-                                                          const uint32_t *__restrict__ partials,
-                                                          uint32_t *__restrict__ offsets,
-                                                          int32_t *__restrict__ active_list)
-{
-    __shared__ uint32_t s_w[2][4];
-    const int base = blockIdx.x * kScanTile + threadIdx.x * 8;
-    uint32_t c[8];
-    uint32_t sum = 0, act = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        int i = base + k;
-        c[k] = i < n ? counts[i] & kCountMask : 0u;
-        sum += c[k];
-        act += c[k] != 0u;
-    }
-    uint32_t is = sum, ia = act, ts, ta;
-    wg_incl_scan2(is, ia, ts, ta, &s_w);
-    uint32_t off = partials[2 * blockIdx.x] + is - sum;
-    uint32_t aoff = partials[2 * blockIdx.x + 1] + ia - act;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        int i = base + k;
-        if (i < n) {
-            offsets[i] = off;
-            if (active_list && c[k] != 0u) active_list[aoff++] = i;
-            off += c[k];
-            if (i == n - 1) offsets[n] = off;
-        }
-    }
-}
-
 // ----------------------------------------------------------------------------------------------
-// scan_fused_kernel: the same exclusive scan + compaction in ONE launch (chained scan with decoupled
-// look-back), the default.  A step of the path is then three dispatches -- classify, scan, emit --
+// scan_fused_kernel: exclusive scan + compaction in ONE launch (chained scan with decoupled look-back).  A step of the path is then three dispatches -- classify, scan, emit --
 // instead of seven plus two copies; what that buys is fixed cost (~35 us per step), which is what
 // strong scaling over 8 GPUs is short of (a rank's kernels take 0.3 ms there).
 //   * tiles are handed out by a ticket taken when a workgroup STARTS, so every predecessor of a tile
@@ -459,21 +372,6 @@ __global__ __launch_bounds__(256) void scan_fused_kernel(const uint32_t *__restr
     }
 }
 
-// Per-volume {vertices, triangles} -- the array a multi-GPU caller all-gathers.  Soup:
-// 3 unique vertices per triangle (VoxelTerrain.cs:456-459); indexed: the welded vertex count of the
-// volume's blocks, from the second scan.
-__global__ void volume_counts_kernel(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ voffsets_or_null,
-                                     int bpv, int n_volumes, uint32_t *__restrict__ volume_counts)
-{
-    int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < n_volumes) {
-        const long long lo = (long long)v * bpv, hi = (long long)(v + 1) * bpv;
-        const uint32_t t = offsets[hi] - offsets[lo];
-        volume_counts[2 * v] = voffsets_or_null ? voffsets_or_null[hi] - voffsets_or_null[lo] : 3u * t;
-        volume_counts[2 * v + 1] = t;
-    }
-}
-
 // ----------------------------------------------------------------------------------------------
 // launch wrappers
 // ----------------------------------------------------------------------------------------------
@@ -508,17 +406,6 @@ hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, u
     return hipGetLastError();
 }
 
-hipError_t launch_scan(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list,
-                       uint32_t *partials, uint32_t *totals, hipStream_t stream)
-{
-    int n_tiles = (n_blocks + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, partials);
-    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(256), 0, stream, partials, n_tiles, totals);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, partials, offsets,
-                       active_list);
-    return hipGetLastError();
-}
-
 hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list, unsigned long long *ctrl,
                              uint32_t *totals, uint32_t *host_totals, uint32_t *zero_words, int n_zero, const uint32_t *vcounts_or_null,
                              uint32_t *voffsets, uint32_t *vtotals, hipStream_t stream)
@@ -531,15 +418,6 @@ hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *off
     else
         hipLaunchKernelGGL((scan_fused_kernel<false>), dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, offsets, active_list, ctrl, totals,
                            host_totals, zero_words, n_zero, nullptr, nullptr, nullptr, nullptr);
-    return hipGetLastError();
-}
-
-hipError_t launch_volume_counts(const uint32_t *offsets, const uint32_t *voffsets_or_null, int bpv, int n_volumes,
-                                uint32_t *volume_counts, hipStream_t stream)
-{
-    if (volume_counts && n_volumes > 0)
-        hipLaunchKernelGGL(volume_counts_kernel, dim3((n_volumes + 255) / 256), dim3(256), 0, stream, offsets, voffsets_or_null, bpv,
-                           n_volumes, volume_counts);
     return hipGetLastError();
 }
 

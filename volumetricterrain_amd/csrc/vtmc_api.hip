@@ -77,31 +77,24 @@ int queue_emit(vtmc_ctx *ctx, bool retry)
     const VtmcPending &pe = ctx->pending;
     hipStream_t stream = pe.stream;
     const bool indexed = pe.indexed;
-    const bool fused = ctx->tune.scan_fused != 0;
     const size_t tcap = std::min<size_t>(indexed ? ctx->indices.bytes / (3 * sizeof(int32_t)) : ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
     const size_t vcap = indexed ? std::min<size_t>(ctx->verts.bytes / sizeof(vtmc_vertex), 0x7fffffffu) : 0;
     ctx->pending.tcap = tcap;
     ctx->pending.vcap = vcap;
     uint32_t *queue = (uint32_t *)ctx->totals.p + 64;
-    if (!fused || retry)   // the fused scan clears the ticket queue on its way
+    if (retry)   // the scan cleared the ticket queue for the first launch
         VTMC_HIP(ctx, hipMemsetAsync(queue, 0, kQueueWords * sizeof(uint32_t), stream));
-    uint32_t *vc = fused && pe.n_volumes > 0 ? (uint32_t *)ctx->volcounts.p : nullptr;
+    uint32_t *vc = pe.n_volumes > 0 ? (uint32_t *)ctx->volcounts.p : nullptr;
     if (indexed)
         VTMC_HIP(ctx, launch_emit_indexed(pe.sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const uint32_t *)ctx->voffsets.p,
                                           (const int32_t *)ctx->active.p, (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->vtotals.p,
-                                          (const uint32_t *)ctx->counts.p, (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p, ctx->indices.p, ctx->n_cus, ctx->tune, queue, vc,
-                                          pe.n_volumes, stream));
+                                          (const uint32_t *)ctx->counts.p, (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p, ctx->indices.p, ctx->n_cus,
+                                          ctx->tune, queue, vc, pe.n_volumes, stream));
     else
         VTMC_HIP(ctx, launch_emit(pe.sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const int32_t *)ctx->active.p,
                                   (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->counts.p, (uint32_t)tcap, ctx->tris.p,
                                   ctx->n_cus, ctx->tune, queue, vc, pe.n_volumes, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
-    if (!fused) {
-        // {T saturating, nActive, T as 64 bits} -- the scan keeps its running total in 64 bits, so a batch
-        // whose triangle count passes 2^32 is reported as such instead of wrapping to a small count
-        VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->totals.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        if (indexed) VTMC_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 4, ctx->vtotals.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    }
     return VTMC_OK;
 }
 
@@ -133,16 +126,15 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     // the emit kernel addresses a tile with 32-bit byte offsets from the block origin
     if ((9.0 * ((double)sp.sx + (double)sp.sy + (double)sp.sz) + 1.0) * 4.0 >= 4294967296.0)
         return fail(ctx, VTMC_ERR_TOO_LARGE, "strides too large: a 10x10x10 tile must span less than 4 GiB");
-    const int n_tiles = (B + kScanTile - 1) / kScanTile;
     if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
     if (int rc = ensure(ctx, ctx->volcounts, sizeof(uint32_t) * 2 * (size_t)std::max(n_volumes, 1))) return rc;
     if (!indexed && !ctx->tris.p)
         if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * ((size_t)1 << 20))) return rc;
     if (int rc = ensure(ctx, ctx->counts, sizeof(uint32_t) * (size_t)B)) return rc;
     if (int rc = ensure(ctx, ctx->active, sizeof(int32_t) * (size_t)B)) return rc;
-    const bool fused = ctx->tune.scan_fused != 0 && B < (1 << 30);   // the status word holds 30 bits of non-empty blocks
+    if (B >= (1 << 30)) return fail(ctx, VTMC_ERR_TOO_LARGE, "more than 2^30 blocks in one batch");   // the scan's status word holds 30 bits of non-empty blocks
     const size_t ctrl_words = scan_ctrl_words(B);
-    if (int rc = ensure(ctx, ctx->partials, std::max(sizeof(uint32_t) * 2 * (size_t)n_tiles, sizeof(unsigned long long) * 2 * ctrl_words))) return rc;
+    if (int rc = ensure(ctx, ctx->partials, sizeof(unsigned long long) * 2 * ctrl_words)) return rc;   // ticket, error word, one or two status words per tile
     if (int rc = ensure(ctx, ctx->totals, sizeof(uint32_t) * (64 + kQueueWords))) return rc;  // scan totals, then the emit kernel's ticket counters
     uint8_t *d_cases = nullptr;
     if (flags & VTMC_FLAG_WANT_CASES) {
@@ -153,7 +145,6 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     if (indexed) {
         if (int rc = ensure(ctx, ctx->vcounts, sizeof(uint32_t) * (size_t)B)) return rc;
         if (int rc = ensure(ctx, ctx->voffsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
-        if (int rc = ensure(ctx, ctx->vpartials, sizeof(uint32_t) * 2 * (size_t)n_tiles)) return rc;   // three-kernel scan only
         if (int rc = ensure(ctx, ctx->vtotals, sizeof(uint32_t) * 64)) return rc;
         if (!ctx->verts.p)
             if (int rc = ensure(ctx, ctx->verts, sizeof(vtmc_vertex) * ((size_t)1 << 19))) return rc;
@@ -163,27 +154,18 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     }
     const bool dense = !sp.list && sp.sx == 1 && sp.nx >= 32 && !(flags & (VTMC_FLAG_WANT_CASES | VTMC_FLAG_NO_DENSE_PATH));
 
-    unsigned long long *ctrl = fused ? (unsigned long long *)ctx->partials.p : nullptr;
-    const int n_ctrl = fused ? (int)(ctrl_words * (indexed ? 2 : 1)) : 0;
-    if (fused) ctx->h_totals[8] = 0u;   // the scan's look-back time-out word
+    unsigned long long *ctrl = (unsigned long long *)ctx->partials.p;
+    const int n_ctrl = (int)(ctrl_words * (indexed ? 2 : 1));
+    ctx->h_totals[8] = 0u;   // the scan's look-back time-out word
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
     if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_vcounts, ctx->tune.classify_ablate, ctrl, n_ctrl, stream));
     else VTMC_HIP(ctx, launch_classify_blocks(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_cases, d_vcounts, ctx->n_cus, ctrl, n_ctrl, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
-    if (fused) {
-        // one launch: offsets, active list, totals (also straight into the host's pinned words), emit queue cleared
-        VTMC_HIP(ctx, launch_scan_fused((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p, (int32_t *)ctx->active.p, ctrl,
-                                        (uint32_t *)ctx->totals.p, ctx->h_totals_dev, (uint32_t *)ctx->totals.p + 64, kQueueWords, d_vcounts,
-                                        indexed ? (uint32_t *)ctx->voffsets.p : nullptr, indexed ? (uint32_t *)ctx->vtotals.p : nullptr, stream));
-    } else {
-        VTMC_HIP(ctx, launch_scan((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p, (int32_t *)ctx->active.p,
-                                  (uint32_t *)ctx->partials.p, (uint32_t *)ctx->totals.p, stream));
-        if (indexed)  // the same scan over the welded-vertex counts: per-block vertex offsets + V
-            VTMC_HIP(ctx, launch_scan(d_vcounts, B, (uint32_t *)ctx->voffsets.p, nullptr, (uint32_t *)ctx->vpartials.p,
-                                      (uint32_t *)ctx->vtotals.p, stream));
-        VTMC_HIP(ctx, launch_volume_counts((const uint32_t *)ctx->offsets.p, indexed ? (const uint32_t *)ctx->voffsets.p : nullptr, sp.bpv,
-                                           n_volumes, (uint32_t *)ctx->volcounts.p, stream));
-    }
+    // one launch: offsets, active list, totals (also straight into the host's pinned words), emit queue cleared; the indexed
+    // output's vertex counts ride along
+    VTMC_HIP(ctx, launch_scan_fused((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p, (int32_t *)ctx->active.p, ctrl,
+                                    (uint32_t *)ctx->totals.p, ctx->h_totals_dev, (uint32_t *)ctx->totals.p + 64, kQueueWords, d_vcounts,
+                                    indexed ? (uint32_t *)ctx->voffsets.p : nullptr, indexed ? (uint32_t *)ctx->vtotals.p : nullptr, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
     pe.active = true;
     pe.launched = true;
@@ -365,7 +347,7 @@ int32_t vtmc_destroy(vtmc_ctx *ctx)
     comm_release(ctx);
     for (DevBuf *b : {&ctx->d_vert, &ctx->d_trinum, &ctx->counts, &ctx->offsets, &ctx->active, &ctx->partials, &ctx->totals,
                       &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->yrows, &ctx->terrain, &ctx->heightmap,
-                      &ctx->vcounts, &ctx->voffsets, &ctx->vpartials, &ctx->vtotals, &ctx->verts, &ctx->indices, &ctx->chunk_image,
+                      &ctx->vcounts, &ctx->voffsets, &ctx->vtotals, &ctx->verts, &ctx->indices, &ctx->chunk_image,
                       &ctx->comm_send})
         release(*b);
     if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
@@ -695,7 +677,6 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     else if (k == "classify_ablate") ctx->tune.classify_ablate = value;
     else if (k == "emit_row_masks") ctx->tune.emit_row_masks = value;
     else if (k == "density_ablate") ctx->tune.density_ablate = value;
-    else if (k == "scan_fused") ctx->tune.scan_fused = value;
     else if (k == "emit_group_log2") ctx->tune.emit_group_log2 = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (k == "emit_wgs_per_cu") ctx->tune.emit_wgs_per_cu = value;
     else return fail(ctx, VTMC_ERR_INVALID_ARG, "unknown tuning key '%s'", key);

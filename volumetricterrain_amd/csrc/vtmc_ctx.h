@@ -31,7 +31,7 @@ struct vtmc_ctx {
     vtmc::DeviceTables tables{nullptr, nullptr};
     VtmcDevBuf d_vert, d_trinum;
     VtmcDevBuf counts, offsets, active, partials, totals, volcounts, cases, tris, input, list, perm, origins, yrows;
-    VtmcDevBuf vcounts, voffsets, vpartials, vtotals, verts, indices;  // indexed output
+    VtmcDevBuf vcounts, voffsets, vtotals, verts, indices;  // indexed output
     int output_mode = VTMC_OUTPUT_SOUP;
     bool last_indexed = false;
     int64_t last_verts = 0;

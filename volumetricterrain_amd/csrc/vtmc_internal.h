@@ -61,7 +61,6 @@ struct Tuning {
     int emit_row_masks = 1;   // emit loads only the tile rows next to cells with triangles (masks from classify)
     int emit_group_log2 = 0;  // each wave takes 2^g consecutive active-list entries per round
     int density_ablate = 0;   // diagnostics only: 1 the sampler skips its stores (output invalid)
-    int scan_fused = 1;       // 1: one-launch chained scan, volume counts in the emit kernel's prologue, totals written to pinned memory; 0: three scan kernels + copies
 };
 
 // scan scratch layout
@@ -86,10 +85,6 @@ hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *off
                              uint32_t *totals, uint32_t *host_totals, uint32_t *zero_words, int n_zero, const uint32_t *vcounts_or_null,
                              uint32_t *voffsets, uint32_t *vtotals, hipStream_t stream);
 inline size_t scan_ctrl_words(int n_blocks) { return 2 + (size_t)((n_blocks + 2047) / 2048); }
-hipError_t launch_scan(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list,
-                       uint32_t *partials, uint32_t *totals, hipStream_t stream);
-hipError_t launch_volume_counts(const uint32_t *offsets, const uint32_t *voffsets_or_null, int bpv, int n_volumes,
-                                uint32_t *volume_counts, hipStream_t stream);
 hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets,
                        const int32_t *active_list, const uint32_t *totals, const uint32_t *counts_or_null, uint32_t capacity,
                        void *triangles, int n_cus, const Tuning &tune, unsigned *queue, uint32_t *volume_counts, int n_volumes,

@@ -117,6 +117,11 @@ class Extractor:
         buffers (read_indexed_mesh) instead of 76-byte records (read_triangles)."""
         self._check(self._L.vtmc_set_output_mode(self._h, 1 if indexed else 0))
 
+    def last_vertex_count(self):
+        nv = ctypes.c_int32()
+        self._check(self._L.vtmc_last_vertex_count(self._h, ctypes.byref(nv)))
+        return nv.value
+
     def read_indexed_mesh(self):
         """(vertices[V], indices[T,3] block-local, block_vertex_offsets[B+1], block_tri_offsets[B+1])."""
         n_blocks, n_tris = self.last_counts()
