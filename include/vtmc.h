@@ -190,10 +190,13 @@ int32_t vtmc_density_fill_device(vtmc_ctx *ctx, const vtmc_density_params *param
 /* ------------------------------------------------------------------------------------------
  * Indexed (welded) output -- new; the reference welds on the CPU afterwards with Mesh.Optimize()
  * (VoxelTerrain.cs:460).  Per block: one vertex per lattice edge with a sign change (all cells
- * around the edge share it), ordered by lattice point x + 9y + 81z then axis; three block-local
- * int32 indices per triangle in the canonical triangle order.  ~24 bytes per triangle instead of 76.
- * De-indexing reproduces the 76-byte records within the 1e-5 bar (the reference evaluates an edge
- * from either end depending on the cell; here always from its low end).
+ * around the edge share it).  Every such edge is a cube edge of exactly one OWNER cell -- the cell
+ * whose corner 0 is the edge's low point (cube edges 0, 3, 8 of MarchingCube.compute:40-43) or, on the
+ * block's x = 8 / y = 8 / z = 8 faces, the boundary cell next to it -- and vertices are ordered by owner
+ * cell x + 8y + 64z, then cube edge id; three block-local int32 indices per triangle in the canonical
+ * triangle order.  ~27 bytes per triangle instead of 76.  De-indexing reproduces the 76-byte records
+ * within the 1e-5 bar (the reference evaluates an edge from either end depending on the cell; here
+ * always from its low end).  Faster than the soup on the benchmark field.
  * ------------------------------------------------------------------------------------------ */
 typedef struct vtmc_vertex {
     float position[3]; /* block-local, cell units [0,8] */
