@@ -72,8 +72,8 @@ def parse():
     else:
         args.n = args.n or 1024
         args.kind = args.kind or "perlin3d"
-        args.steps = 20 if args.steps is None else args.steps
-        args.warmup = 3 if args.warmup is None else args.warmup
+        args.steps = 100 if args.steps is None else args.steps   # ~0.2 s of timed region: long enough for a power / busy sample to see it
+        args.warmup = 5 if args.warmup is None else args.warmup
     return args
 
 

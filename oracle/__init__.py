@@ -34,13 +34,23 @@ class DensityParams(ctypes.Structure):
 
 
 def build(force=False):
+    """make under a file lock: the ranks of a torchrun job and pytest-xdist workers all call this."""
+    import fcntl
     srcs = [os.path.join(_HERE, f) for f in ("mc_oracle.c", "density_ref.c", "terrain_ref.c", "mc_oracle.h", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "volumetricterrain_amd", "csrc", "mc_tables_packed.h"))
-    stale = force or not os.path.exists(_SO) or any(
-        os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs if os.path.exists(s))
-    if stale:
-        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
-                       stdout=subprocess.DEVNULL)
+
+    def stale():
+        return force or not os.path.exists(_SO) or any(
+            os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs if os.path.exists(s))
+
+    if stale():
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if stale():   # not built by another process while this one waited
+                    subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True, stdout=subprocess.DEVNULL)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return _SO
 
 
