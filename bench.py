@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: the same 1024^3 world sharded (BASELINE configs[3]) or 512 chunks per rank")
     ap.add_argument("--grid", "--n", dest="n", type=int, default=None, help="cells per axis (reduced sizes for tests)")
     ap.add_argument("--chunk", type=int, default=128, help="cells per axis of a chunk")
-    ap.add_argument("--batch", type=int, default=64, help="stream2048: chunks per double-buffered batch")
+    ap.add_argument("--batch", type=int, default=128, help="stream2048: chunks per double-buffered batch")
     ap.add_argument("--kind", default=None, choices=["perlin3d", "fbm8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chunks", type=int, default=32, help="chunks the CPU oracle is timed on")
