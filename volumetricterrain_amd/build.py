@@ -17,8 +17,11 @@ LIB = os.path.join(HERE, "libvtmc.so")
 SOURCES = ["vtmc_api.hip", "classify_kernels.hip", "emit_kernels.hip", "terrain.hip", "density.hip",
            "chunk_io.hip", "comm.hip"]
 HEADERS = ["vtmc_internal.h", "vtmc_ctx.h", "mc_device.h", "emit_device.h", "mc_tables_packed.h", os.path.join("..", "..", "include", "vtmc.h")]
+# -fno-slp-vectorize: hipcc's SLP pass packs adjacent FP32 operations into v_pk_fma_f32 / v_pk_add_f32 (+ moves to
+# pair the operands); on gfx950 a packed FP32 op costs more than the two scalar ones it replaces
+# (MI355X_MICROARCH.md, "packed f32 VALU ... an anti-lever"): the sampler runs 30 % faster without it.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
 
 
 def is_stale():
