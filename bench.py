@@ -210,15 +210,34 @@ def init_distributed(args, torch, dist):
     return rank, world, local, backend
 
 
-def native_comm(ex, rank, world, backend, dist):
+def native_comm(ex, rank, world, backend, dist, torch):
     """The library's own RCCL communicator (vtmc_comm_init_rank): rank 0 draws the id, torch.distributed
     only carries its 128 bytes to the other ranks.  Returns False when the native path is unavailable
-    (VTMC_BENCH_NATIVE_RCCL=0, or two ranks rehearsing on one device), the torch collective is used then."""
+    (VTMC_BENCH_NATIVE_RCCL=0, two ranks rehearsing on one device, or any rank failing to join -- the ranks
+    agree on that with one all-reduce), the torch collective is used then."""
     if world == 1 or os.environ.get("VTMC_BENCH_NATIVE_RCCL", "1") != "1" or backend != "nccl":
         return False
-    box = [ex.comm_unique_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = ex.comm_unique_id()
+        except Exception as e:   # noqa: BLE001 -- e.g. librccl missing: every rank takes the fallback
+            print("native RCCL unavailable (%s): falling back to torch.distributed" % e, file=sys.stderr)
     dist.broadcast_object_list(box, src=0)
-    ex.comm_init_rank(box[0], rank, world)
+    if box[0] is None:
+        return False
+    ok = 1
+    try:
+        ex.comm_init_rank(box[0], rank, world)
+    except Exception as e:   # noqa: BLE001
+        print("rank %d: vtmc_comm_init_rank failed (%s)" % (rank, e), file=sys.stderr)
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag[0]) == 0:
+        if ok:
+            ex.comm_destroy()
+        return False
     return True
 
 
@@ -264,7 +283,7 @@ def run_grid(args, torch, dist):
     sampler_s = time.perf_counter() - t0
     sampler_kernel_ms = ex.last_fill_ms()
 
-    native = native_comm(ex, rank, world, backend, dist)
+    native = native_comm(ex, rank, world, backend, dist, torch)
     flags = 2 if args.no_dense else 0
     gathered = torch.zeros((world, per_rank, 2), dtype=torch.int32, device="cuda")
     gathered_host = torch.zeros((world, per_rank, 2), dtype=torch.int32).pin_memory()
