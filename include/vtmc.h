@@ -162,7 +162,7 @@ int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4]);
 /* Selects a kernel variant / launch shape, mainly for A/B measurements in one process.  Keys that
  * keep results within the parity bar: "emit_fast_math" (1: v_rcp / v_rsq / fma, default; 0: correctly
  * rounded, bit-compatible with the CPU oracle), "emit_wgs_per_cu", "emit_dynamic",
- * "emit_sub_log2", "emit_group_log2".  "emit_ablate" / "classify_ablate" switch parts of a kernel
+ * "emit_sub_log2", "emit_group_log2", "gather_beside".  "emit_ablate" / "classify_ablate" switch parts of a kernel
  * off for diagnosis and make the output INVALID.  Defaults are the shipped configuration. */
 int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value);
 
@@ -313,7 +313,12 @@ int32_t vtmc_comm_destroy(vtmc_ctx *ctx);
 /* All-gather of volume_counts of the last extract_* on `stream` (NULL = the context's stream),
  * asynchronously: d_all_counts (device, world_size x volumes_per_rank x {vertices, triangles} u32)
  * receives rank r's pairs at [r * volumes_per_rank ...), zero-padded where a rank owns fewer volumes.
- * No host synchronisation: the caller orders later work on the same stream. */
+ * No host synchronisation: the caller orders later work on the same stream.
+ * Queued behind vtmc_extract_volumes_device_async (before vtmc_extract_finish) whose chunks are whole
+ * scan tiles (a multiple of 2048 blocks, e.g. 128^3 cells), the counts have already left the scan
+ * kernel: the collective then runs on the context's second stream BESIDE the emit kernel (launched a
+ * workgroup per XCD short for it) and `stream` merely waits for its end (tuning key "gather_beside",
+ * default 1).  Otherwise it runs on `stream`, behind the emit kernel. */
 int32_t vtmc_allgather_volume_counts(vtmc_ctx *ctx, uint32_t *d_all_counts, int32_t volumes_per_rank, void *stream);
 
 /* Blocking device -> host copy on `stream` (NULL = the context's stream) through the library's own

@@ -517,32 +517,43 @@ def test_streaming_shards_cover_the_world(ex, oracle_mod):
     assert np.array_equal(merged, counts)
 
 
-def test_rccl_allgather_of_counts_through_the_c_abi(ex, oracle_mod):
+@pytest.mark.parametrize("c,n_vol,per_rank,indexed", [(32, 3, 5, False), (128, 2, 2, False), (128, 3, 4, True), (32, 3, 3, True)])
+def test_rccl_allgather_of_counts_through_the_c_abi(ex, oracle_mod, c, n_vol, per_rank, indexed):
     """The path's one collective behind the C ABI (vtmc_comm_* + vtmc_allgather_volume_counts): a
     world of one rank round-trips its per-chunk {vertices, triangles} through RCCL, padded to
-    volumes_per_rank.  (Two ranks on one device are refused by RCCL; the multi-rank path is the same
-    call with world_size > 1 and is covered on CPU by tests/test_sharding_gloo.py's layout checks.)"""
+    volumes_per_rank.  128^3 chunks are whole scan tiles, so there the counts leave the scan kernel and
+    the collective is queued on the context's second stream beside the emit kernel; 32^3 chunks take the
+    emit-prologue route on the caller's stream.  (Two ranks on one device are refused by RCCL; the
+    multi-rank path is the same call with world_size > 1 and is covered on CPU by
+    tests/test_sharding_gloo.py's layout checks.)"""
     import torch
     import volumetricterrain_amd as vt
-    c, dim = 32, 34
-    chunks = [oracle_mod.density_volume("perlin3d", c, origin=(32 * i, 0, 0)) for i in range(3)]
+    dim = c + 2
+    chunks = [oracle_mod.density_volume("perlin3d", c, origin=(c * i, 0, c)) for i in range(n_vol)]
     d = torch.from_numpy(np.stack([np.ascontiguousarray(g.transpose(2, 1, 0)) for g in chunks])).cuda()
     want = [oracle_mod.extract_grid(g, count_only=True)[0] for g in chunks]
+    want_v = [len(oracle_mod.extract_grid_indexed(g)[0]) for g in chunks] if indexed else [3 * t for t in want]
     with vt.Extractor(0) as e2:
+        e2.set_output_mode(indexed)
         with pytest.raises(vt.VtmcError) as err:
             e2.allgather_volume_counts(0, 4)
         assert err.value.code == -5                       # no communicator yet
         e2.comm_init_rank(e2.comm_unique_id(), 0, 1)
-        gathered = torch.full((1, 5, 2), 0x7FFFFFFF, dtype=torch.int32, device="cuda")
-        e2.extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 3, dim ** 3)
-        e2.allgather_volume_counts(gathered.data_ptr(), 5)     # queued behind the scan of the pending extract
-        T = e2.extract_finish()
-        torch.cuda.synchronize()
-        g = gathered.cpu().numpy()[0]
-        assert T == sum(want) and list(g[:3, 1]) == want and np.array_equal(g[:3, 0], 3 * g[:3, 1])
-        assert not g[3:].any()                             # zero padding up to volumes_per_rank
+        for rep in range(2):                               # the second round reuses the streams, events and send buffer
+            gathered = torch.full((1, per_rank, 2), 0x7FFFFFFF, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            e2.extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), n_vol, dim ** 3)
+            e2.allgather_volume_counts(gathered.data_ptr(), per_rank)     # queued behind the scan of the pending extract
+            host = e2.copy_u32(gathered.data_ptr(), 2 * per_rank).reshape(per_rank, 2)   # on the extract's stream: waits for the collective
+            T = e2.extract_finish()
+            assert T == sum(want) and list(host[:n_vol, 1]) == want and list(host[:n_vol, 0]) == want_v
+            assert not host[n_vol:].any()                  # zero padding up to volumes_per_rank
+        # after finish() the same call gathers the finished extract's counts on the caller's stream
+        e2.allgather_volume_counts(gathered.data_ptr(), per_rank)
+        host = e2.copy_u32(gathered.data_ptr(), 2 * per_rank).reshape(per_rank, 2)
+        assert list(host[:n_vol, 1]) == want
         with pytest.raises(vt.VtmcError) as err:
-            e2.allgather_volume_counts(gathered.data_ptr(), 2)
+            e2.allgather_volume_counts(gathered.data_ptr(), n_vol - 1)
         assert err.value.code == -3
         e2.comm_destroy()
 

@@ -2,7 +2,9 @@
 """Strong-scaling rehearsal on ONE GPU: times the step of rank r of a W-rank run of BASELINE configs[3]
 (its 512 / W chunks of the 1024^3 world: queued extract + the one host wait, no collective) next to the
 whole 512-chunk step, i.e. the speed-up the sharding leaves before the all-gather's ~tens of microseconds.
-    python tools/rank_step.py [W ...]"""
+    python tools/rank_step.py [--comm | --comm-behind] [W ...]
+--comm: every step also queues the C ABI's all-gather (a world-of-one RCCL communicator: the library's second
+stream, its events and the copy of the gathered array are real, the wire is not) -- the fixed cost of the exchange."""
 import os
 import sys
 import time
@@ -18,15 +20,27 @@ stream = torch.cuda.Stream()
 torch.cuda.set_stream(stream)
 prm = vt.density_params("perlin3d", n)
 out = {}
-for W in [1] + [int(a) for a in sys.argv[1:] or ["2", "4", "8"]]:
+args = [a for a in sys.argv[1:] if not a.startswith("--comm")]
+with_comm = any(a.startswith("--comm") for a in sys.argv[1:])
+if with_comm:
+    ex.comm_init_rank(ex.comm_unique_id(), 0, 1)
+    if "--comm-behind" in sys.argv[1:]:
+        ex.set_tuning(gather_beside=0)   # round 2a's order: the collective behind the emit kernel on the same stream
+for W in [1] + [int(a) for a in args or ["2", "4", "8"]]:
     worst = 0.0
     for r in range(W):
         org = sharding.chunk_origins(n, c, r, W)
         d = torch.empty(len(org) * dim ** 3, dtype=torch.float32, device="cuda")
         ex.density_fill_device(prm, org, (dim, dim, dim), (1, dim, dim * dim), dim ** 3, d.data_ptr(), stream.cuda_stream)
 
+        gathered = torch.zeros(2 * len(org), dtype=torch.int32, device="cuda")
+        gathered_host = torch.zeros(2 * len(org), dtype=torch.int32).pin_memory()
+
         def step():
             ex.extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), len(org), dim ** 3, stream.cuda_stream, 0)
+            if with_comm:
+                ex.allgather_volume_counts(gathered.data_ptr(), len(org), stream.cuda_stream)
+                gathered_host.copy_(gathered, non_blocking=True)   # as bench.py: behind the collective, before the one wait
             return ex.extract_finish()
 
         for _ in range(3):

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256) void scan_fused_kernel(const uint32_t *__restr
                                                           uint32_t *__restrict__ totals, uint32_t *__restrict__ host_totals,
                                                           uint32_t *__restrict__ zero_words, int n_zero,
                                                           const uint32_t *__restrict__ vcounts, uint32_t *__restrict__ voffsets,
-                                                          unsigned long long *__restrict__ vstatus, uint32_t *__restrict__ vtotals)
+                                                          unsigned long long *__restrict__ vstatus, uint32_t *__restrict__ vtotals,
+                                                          uint32_t *__restrict__ volume_counts, int tiles_per_volume)
 {
     __shared__ uint32_t s_w[2][4];
     __shared__ uint32_t s_v[4];
@@ -336,6 +337,40 @@ __global__ __launch_bounds__(256) void scan_fused_kernel(const uint32_t *__restr
             s_ex_tri = ex_tri;
             s_ex_act = ex_act;
             s_ex_vert = ex_vert;
+            // Per-volume {vertices, triangles} as soon as the scan knows them -- a multi-GPU caller's
+            // all-gather then runs beside the emit kernel instead of behind it.  Possible when a volume is a whole
+            // number of tiles: the tile that ends volume v subtracts the inclusive prefix of the tile that ends v - 1,
+            // read from its (self-describing) status word once that has turned inclusive.
+            if (volume_counts && tiles_per_volume > 0 && (t + 1) % tiles_per_volume == 0 && !failed) {
+                const int v = (t + 1) / tiles_per_volume - 1, tp = t - tiles_per_volume;
+                unsigned long long ptri = 0, pvert = 0;
+                bool ok = true;
+                if (tp >= 0) {
+                    unsigned long long w = 0, wv = kScanInclusive;
+                    int spins = 0;
+                    for (;;) {
+                        w = __hip_atomic_load(&status[tp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (DUAL) wv = __hip_atomic_load(&vstatus[tp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((w >> 62) == 2ull && (wv >> 62) == 2ull) break;
+                        if (++spins > kScanSpinLimit) {
+                            ok = false;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    ptri = w & 0xFFFFFFFFull;
+                    pvert = wv & 0x3FFFFFFFFFFFFFFFull;
+                }
+                if (ok) {
+                    const uint32_t tv_ = (uint32_t)(ex_tri + ts - ptri);
+                    volume_counts[2 * v + 1] = tv_;
+                    volume_counts[2 * v] = DUAL ? (uint32_t)(ex_vert + tv - pvert) : 3u * tv_;   // soup: 3 vertices per triangle (VoxelTerrain.cs:456-459)
+                } else {
+                    reinterpret_cast<unsigned *>(ctrl + 1)[0] = 1u;
+                    totals[8] = 1u;
+                    if (host_totals) host_totals[8] = 1u;
+                }
+            }
         }
     }
     __syncthreads();
@@ -408,16 +443,17 @@ hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, u
 
 hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list, unsigned long long *ctrl,
                              uint32_t *totals, uint32_t *host_totals, uint32_t *zero_words, int n_zero, const uint32_t *vcounts_or_null,
-                             uint32_t *voffsets, uint32_t *vtotals, hipStream_t stream)
+                             uint32_t *voffsets, uint32_t *vtotals, uint32_t *volume_counts_or_null, int bpv, hipStream_t stream)
 {
     const int n_tiles = (n_blocks + kScanTile - 1) / kScanTile;
     unsigned long long *vstatus = ctrl + scan_ctrl_words(n_blocks);   // the second half of the control words
+    const int tpv = (volume_counts_or_null && bpv > 0 && bpv % kScanTile == 0) ? bpv / kScanTile : 0;
     if (vcounts_or_null)
         hipLaunchKernelGGL((scan_fused_kernel<true>), dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, offsets, active_list, ctrl, totals,
-                           host_totals, zero_words, n_zero, vcounts_or_null, voffsets, vstatus, vtotals);
+                           host_totals, zero_words, n_zero, vcounts_or_null, voffsets, vstatus, vtotals, volume_counts_or_null, tpv);
     else
         hipLaunchKernelGGL((scan_fused_kernel<false>), dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, offsets, active_list, ctrl, totals,
-                           host_totals, zero_words, n_zero, nullptr, nullptr, nullptr, nullptr);
+                           host_totals, zero_words, n_zero, nullptr, nullptr, nullptr, nullptr, volume_counts_or_null, tpv);
     return hipGetLastError();
 }
 

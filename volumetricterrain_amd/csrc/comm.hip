@@ -119,6 +119,7 @@ int32_t vtmc_comm_destroy(vtmc_ctx *ctx)
 {
     if (!ctx) return VTMC_ERR_INVALID_ARG;
     if (ctx->stream) VTMC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_stream) VTMC_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
     comm_release(ctx);
     return VTMC_OK;
 }
@@ -138,15 +139,37 @@ int32_t vtmc_allgather_volume_counts(vtmc_ctx *ctx, uint32_t *d_all_counts, int3
     const RcclApi &a = rccl();
     VTMC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    // When the scan of a queued extract has already left the counts (whole scan tiles per volume), the
+    // collective goes to the context's second stream behind the scan's event and runs BESIDE the emit
+    // kernel, which was launched a workgroup per XCD short for it; `stream` then only waits for its end.
+    const bool beside = ctx->pending.active && ctx->pending.launched && ctx->pending.counts_early && ctx->tune.gather_beside;
+    hipStream_t gs = st;
+    if (beside) {
+        if (!ctx->comm_stream) VTMC_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+        if (!ctx->ev_gather) VTMC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_gather, hipEventDisableTiming));
+        gs = ctx->comm_stream;
+        VTMC_HIP(ctx, hipStreamWaitEvent(gs, ctx->ev[2], 0));
+    }
     // ranks may own different numbers of chunks (c % N): every rank sends volumes_per_rank pairs, zero-padded
     const size_t words = 2 * (size_t)volumes_per_rank;
-    if (ctx->comm_send.bytes < words * sizeof(uint32_t)) VTMC_HIP(ctx, hipStreamSynchronize(st));  // about to reallocate
-    if (int rc = ensure(ctx, ctx->comm_send, words * sizeof(uint32_t))) return rc;
     const size_t own = 2 * (size_t)(n_blk > 0 ? n_vol : 0);
-    if (own < words) VTMC_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->comm_send.p + own, 0, (words - own) * sizeof(uint32_t), st));
-    if (own > 0)
-        VTMC_HIP(ctx, hipMemcpyAsync(ctx->comm_send.p, ctx->volcounts.p, own * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-    VTMC_NCCL(ctx, a, a.AllGather(ctx->comm_send.p, d_all_counts, words, ncclUint32, (ncclComm_t)ctx->comm, st));
+    const void *send = ctx->volcounts.p;
+    if (own < words) {
+        if (ctx->comm_send.bytes < words * sizeof(uint32_t)) {   // about to reallocate
+            VTMC_HIP(ctx, hipStreamSynchronize(st));
+            if (ctx->comm_stream) VTMC_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
+        }
+        if (int rc = ensure(ctx, ctx->comm_send, words * sizeof(uint32_t))) return rc;
+        VTMC_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->comm_send.p + own, 0, (words - own) * sizeof(uint32_t), gs));
+        if (own > 0)
+            VTMC_HIP(ctx, hipMemcpyAsync(ctx->comm_send.p, ctx->volcounts.p, own * sizeof(uint32_t), hipMemcpyDeviceToDevice, gs));
+        send = ctx->comm_send.p;
+    }
+    VTMC_NCCL(ctx, a, a.AllGather(send, d_all_counts, words, ncclUint32, (ncclComm_t)ctx->comm, gs));
+    if (beside) {
+        VTMC_HIP(ctx, hipEventRecord(ctx->ev_gather, gs));
+        VTMC_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_gather, 0));
+    }
     return VTMC_OK;
 }
 

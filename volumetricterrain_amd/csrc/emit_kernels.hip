@@ -183,6 +183,7 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
     int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : 4;  // 4 x 40 KB of LDS, 128 VGPRs
     int wgs = n_cus * per_cu;
     wgs = (wgs + 7) & ~7;  // the XCD sweep needs a multiple of 8
+    if (wgs > 8 + tune.emit_spare_wgs) wgs -= tune.emit_spare_wgs & ~7;
     dim3 g(wgs), blk(256);
     float *o = (float *)triangles;
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
@@ -202,6 +203,7 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
     int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : 4;   // 39.9 KB of LDS, <= 128 VGPRs
     int wgs = n_cus * per_cu;
     wgs = (wgs + 7) & ~7;
+    if (wgs > 8 + tune.emit_spare_wgs) wgs -= tune.emit_spare_wgs & ~7;
     dim3 g(wgs), blk(256);
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
     if (tune.emit_fast_math)

@@ -84,16 +84,18 @@ int queue_emit(vtmc_ctx *ctx, bool retry)
     uint32_t *queue = (uint32_t *)ctx->totals.p + 64;
     if (retry)   // the scan cleared the ticket queue for the first launch
         VTMC_HIP(ctx, hipMemsetAsync(queue, 0, kQueueWords * sizeof(uint32_t), stream));
-    uint32_t *vc = pe.n_volumes > 0 ? (uint32_t *)ctx->volcounts.p : nullptr;
+    uint32_t *vc = pe.n_volumes > 0 && !pe.counts_early ? (uint32_t *)ctx->volcounts.p : nullptr;   // else the scan has left them already
+    Tuning tune = ctx->tune;
+    if (ctx->comm && pe.counts_early && ctx->tune.gather_beside) tune.emit_spare_wgs = 8;   // vtmc_allgather_volume_counts runs its kernel beside this one
     if (indexed)
         VTMC_HIP(ctx, launch_emit_indexed(pe.sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const uint32_t *)ctx->voffsets.p,
                                           (const int32_t *)ctx->active.p, (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->vtotals.p,
                                           (const uint32_t *)ctx->counts.p, (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p, ctx->indices.p, ctx->n_cus,
-                                          ctx->tune, queue, vc, pe.n_volumes, stream));
+                                          tune, queue, vc, pe.n_volumes, stream));
     else
         VTMC_HIP(ctx, launch_emit(pe.sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const int32_t *)ctx->active.p,
                                   (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->counts.p, (uint32_t)tcap, ctx->tris.p,
-                                  ctx->n_cus, ctx->tune, queue, vc, pe.n_volumes, stream));
+                                  ctx->n_cus, tune, queue, vc, pe.n_volumes, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
     return VTMC_OK;
 }
@@ -162,10 +164,12 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     else VTMC_HIP(ctx, launch_classify_blocks(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_cases, d_vcounts, ctx->n_cus, ctrl, n_ctrl, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
     // one launch: offsets, active list, totals (also straight into the host's pinned words), emit queue cleared; the indexed
-    // output's vertex counts ride along
+    // output's vertex counts ride along, and so do the per-volume counts when every volume is a whole number of scan tiles
+    pe.counts_early = n_volumes > 0 && scan_writes_volume_counts(sp.bpv) && (long long)sp.bpv * n_volumes == (long long)B;
     VTMC_HIP(ctx, launch_scan_fused((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p, (int32_t *)ctx->active.p, ctrl,
                                     (uint32_t *)ctx->totals.p, ctx->h_totals_dev, (uint32_t *)ctx->totals.p + 64, kQueueWords, d_vcounts,
-                                    indexed ? (uint32_t *)ctx->voffsets.p : nullptr, indexed ? (uint32_t *)ctx->vtotals.p : nullptr, stream));
+                                    indexed ? (uint32_t *)ctx->voffsets.p : nullptr, indexed ? (uint32_t *)ctx->vtotals.p : nullptr,
+                                    pe.counts_early ? (uint32_t *)ctx->volcounts.p : nullptr, sp.bpv, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
     pe.active = true;
     pe.launched = true;
@@ -355,6 +359,8 @@ int32_t vtmc_destroy(vtmc_ctx *ctx)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->ev_fill)
         if (ev) (void)hipEventDestroy(ev);
+    if (ctx->ev_gather) (void)hipEventDestroy(ctx->ev_gather);
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VTMC_OK;
@@ -677,6 +683,7 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     else if (k == "classify_ablate") ctx->tune.classify_ablate = value;
     else if (k == "emit_row_masks") ctx->tune.emit_row_masks = value;
     else if (k == "density_ablate") ctx->tune.density_ablate = value;
+    else if (k == "gather_beside") ctx->tune.gather_beside = value;
     else if (k == "emit_group_log2") ctx->tune.emit_group_log2 = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (k == "emit_wgs_per_cu") ctx->tune.emit_wgs_per_cu = value;
     else return fail(ctx, VTMC_ERR_INVALID_ARG, "unknown tuning key '%s'", key);

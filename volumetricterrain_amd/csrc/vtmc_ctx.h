@@ -22,6 +22,7 @@ struct VtmcPending {
     bool indexed = false;
     hipStream_t stream = nullptr;
     size_t tcap = 0, vcap = 0;  // capacities the last emit launch was given
+    bool counts_early = false;  // the per-volume counts were final when ev[2] (end of the scan) was recorded
 };
 
 struct vtmc_ctx {
@@ -64,6 +65,8 @@ struct vtmc_ctx {
     void *comm = nullptr;
     int comm_rank = 0, comm_world = 1;
     VtmcDevBuf comm_send;
+    hipStream_t comm_stream = nullptr;   // the all-gather runs here, beside the emit kernel, when the counts leave the scan
+    hipEvent_t ev_gather = nullptr;
     std::string err;
 };
 

@@ -61,6 +61,8 @@ struct Tuning {
     int emit_row_masks = 1;   // emit loads only the tile rows next to cells with triangles (masks from classify)
     int emit_group_log2 = 0;  // each wave takes 2^g consecutive active-list entries per round
     int density_ablate = 0;   // diagnostics only: 1 the sampler skips its stores (output invalid)
+    int gather_beside = 1;    // 1: the all-gather of a queued extract runs on a second stream beside the emit kernel; 0: behind it
+    int emit_spare_wgs = 0;   // workgroups the emit launch leaves free (one per XCD: room for the collective's kernel beside it)
 };
 
 // scan scratch layout
@@ -83,7 +85,9 @@ hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, u
 // host_totals[4..7]); ctrl then holds 2 * scan_ctrl_words(n_blocks) zeroed words
 hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list, unsigned long long *ctrl,
                              uint32_t *totals, uint32_t *host_totals, uint32_t *zero_words, int n_zero, const uint32_t *vcounts_or_null,
-                             uint32_t *voffsets, uint32_t *vtotals, hipStream_t stream);
+                             uint32_t *voffsets, uint32_t *vtotals, uint32_t *volume_counts_or_null, int bpv, hipStream_t stream);
+// the scan itself leaves the per-volume counts when a volume is a whole number of scan tiles (else the emit kernel's prologue does)
+inline bool scan_writes_volume_counts(int bpv) { return bpv > 0 && bpv % 2048 == 0; }
 inline size_t scan_ctrl_words(int n_blocks) { return 2 + (size_t)((n_blocks + 2047) / 2048); }
 hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets,
                        const int32_t *active_list, const uint32_t *totals, const uint32_t *counts_or_null, uint32_t capacity,
