@@ -424,7 +424,7 @@ hipError_t launch_classify_blocks(const BlockSpace &sp, const DeviceTables &tb, 
 }
 
 hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
-                                 uint32_t *vcounts_or_null, int ablate, unsigned long long *scan_ctrl, int n_scan_ctrl,
+                                 uint32_t *vcounts_or_null, int ablate, int wgs_per_cu, unsigned long long *scan_ctrl, int n_scan_ctrl,
                                  hipStream_t stream)
 {
     const int nsegx = (sp.nx + 63) / 64;
@@ -432,11 +432,14 @@ hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, u
     long long n_bricks = n_vol * sp.nbz * sp.nby * nsegx;
     long long n_wgs = (n_bricks + kWavesPerWg - 1) / kWavesPerWg;
     if (n_wgs > 0x7fffffffll) return hipErrorInvalidValue;
+    // Residency cap: the kernel needs 65 VGPRs and 256 bytes of LDS, so seven workgroups fit a CU -- and the stream runs
+    // faster with fewer (each wave already keeps 81 row loads in flight).  Unused dynamic LDS is what caps it.
+    const size_t dyn = wgs_per_cu > 0 && wgs_per_cu < 8 ? (size_t)(160 * 1024 / wgs_per_cu - 1024) & ~(size_t)255 : 0;
     if (vcounts_or_null)
-        hipLaunchKernelGGL((classify_dense_kernel<true>), dim3((unsigned)n_wgs), dim3(256), 0, stream, sp, tb, counts, vcounts_or_null,
+        hipLaunchKernelGGL((classify_dense_kernel<true>), dim3((unsigned)n_wgs), dim3(256), dyn, stream, sp, tb, counts, vcounts_or_null,
                            nsegx, (int)n_bricks, (int)n_wgs, ablate, scan_ctrl, n_scan_ctrl);
     else
-        hipLaunchKernelGGL((classify_dense_kernel<false>), dim3((unsigned)n_wgs), dim3(256), 0, stream, sp, tb, counts, vcounts_or_null,
+        hipLaunchKernelGGL((classify_dense_kernel<false>), dim3((unsigned)n_wgs), dim3(256), dyn, stream, sp, tb, counts, vcounts_or_null,
                            nsegx, (int)n_bricks, (int)n_wgs, ablate, scan_ctrl, n_scan_ctrl);
     return hipGetLastError();
 }

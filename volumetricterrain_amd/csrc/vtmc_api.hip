@@ -156,11 +156,11 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     }
     const bool dense = !sp.list && sp.sx == 1 && sp.nx >= 32 && !(flags & (VTMC_FLAG_WANT_CASES | VTMC_FLAG_NO_DENSE_PATH));
 
+    ctx->h_totals[8] = 0u;   // the scan's look-back time-out word
     unsigned long long *ctrl = (unsigned long long *)ctx->partials.p;
     const int n_ctrl = (int)(ctrl_words * (indexed ? 2 : 1));
-    ctx->h_totals[8] = 0u;   // the scan's look-back time-out word
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
-    if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_vcounts, ctx->tune.classify_ablate, ctrl, n_ctrl, stream));
+    if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_vcounts, ctx->tune.classify_ablate, ctx->tune.classify_wgs_per_cu, ctrl, n_ctrl, stream));
     else VTMC_HIP(ctx, launch_classify_blocks(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_cases, d_vcounts, ctx->n_cus, ctrl, n_ctrl, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
     // one launch: offsets, active list, totals (also straight into the host's pinned words), emit queue cleared; the indexed
@@ -684,6 +684,7 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     else if (k == "emit_row_masks") ctx->tune.emit_row_masks = value;
     else if (k == "density_ablate") ctx->tune.density_ablate = value;
     else if (k == "gather_beside") ctx->tune.gather_beside = value;
+    else if (k == "classify_wgs_per_cu") ctx->tune.classify_wgs_per_cu = value;
     else if (k == "emit_group_log2") ctx->tune.emit_group_log2 = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (k == "emit_wgs_per_cu") ctx->tune.emit_wgs_per_cu = value;
     else return fail(ctx, VTMC_ERR_INVALID_ARG, "unknown tuning key '%s'", key);

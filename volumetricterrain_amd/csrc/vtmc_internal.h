@@ -58,6 +58,7 @@ struct Tuning {
     int emit_dynamic = 1;     // per-XCD ticket counters instead of a static round-robin over the active list
     int emit_ablate = 0;      // diagnostics only: 1 skip stores, 2 re-read hot tiles, 4 skip vertex math (output invalid)
     int classify_ablate = 0;  // diagnostics only: 1 no halo rows (output invalid)
+    int classify_wgs_per_cu = 3;   // residency cap of the streaming classify kernel (0: none = 7 workgroups per CU; 3 measured best, A/B in profiles/r02c)
     int emit_row_masks = 1;   // emit loads only the tile rows next to cells with triangles (masks from classify)
     int emit_group_log2 = 0;  // each wave takes 2^g consecutive active-list entries per round
     int density_ablate = 0;   // diagnostics only: 1 the sampler skips its stores (output invalid)
@@ -76,7 +77,7 @@ hipError_t launch_classify_blocks(const BlockSpace &sp, const DeviceTables &tb, 
                                   uint8_t *cases_or_null, uint32_t *vcounts_or_null, int n_cus, unsigned long long *scan_ctrl,
                                   int n_scan_ctrl, hipStream_t stream);
 hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
-                                 uint32_t *vcounts_or_null, int ablate, unsigned long long *scan_ctrl, int n_scan_ctrl,
+                                 uint32_t *vcounts_or_null, int ablate, int wgs_per_cu, unsigned long long *scan_ctrl, int n_scan_ctrl,
                                  hipStream_t stream);
 // one-launch scan: ctrl = 2 + n_tiles words zeroed beforehand (ticket, error, tile status); totals[0..3] = {T saturating, nActive,
 // T, 0}, totals[8] = 1 on a look-back time-out, mirrored into host_totals (device-visible pinned memory) when not null;
