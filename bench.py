@@ -44,7 +44,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
-VALU_PEAK_LANE_OPS = 78.6e12  # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (157.3 TFLOP/s FP32 vector = 2 flops per fma)
+# vector-ALU issue peak for plain (non-packed) FP32 instructions: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.  The guide's 157.3 TFLOP/s
+# FP32 vector figure is twice that and needs v_pk_fma_f32 on both halves; measured on this kernel, packed FP32 was slower.
+VALU_PEAK_LANE_OPS = 39.3e12
 
 
 def parse():
@@ -505,9 +507,11 @@ def run_stream(args, torch, dist):
             alg_bytes = 76.0 * total / nb           # + 4000 B per non-empty block, not counted here
         avg_ms = kern[dom] / nb
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-        # the sampler's own bound is the vector ALU: ~5 lane-ops per sample-octave in a cell, ~45 per face rebuild
-        # (4 / 2048 * 2^o rebuilds per sample at octave o) -- DESIGN.md; reported next to the HBM figure
-        lane_ops = samples * sum(5.0 + 45.0 * min(1.0, st.params.frequency * (st.params.lacunarity ** o)) for o in range(octaves)) + 6.0 * samples
+        # the sampler's own bound is the vector ALU.  Instructions per sample, counted in the kernel's ISA: 3 fmas per
+        # octave + 8 for the step (row unpack, store, loop); a face rebuild is 43, at f * lacunarity^o rebuilds per sample and
+        # octave; a step with any rebuild re-adds the octaves' constants.  Reported next to the HBM figure.
+        rates = [min(1.0, st.params.frequency * (st.params.lacunarity ** o)) for o in range(octaves)]
+        lane_ops = samples * (3.0 * octaves + 8.0 + 43.0 * sum(rates) + octaves * max(rates))
         out = {
             "metric": "streamed sampler + marching-cubes extraction throughput on a %d^3 %s world (Mvoxels/s)" % (n, args.kind),
             "value": round(cells_total / step_s / 1e6, 1),

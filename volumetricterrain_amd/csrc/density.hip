@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void density_row_kernel(DensityLaunch dl, cons
 struct ColOct {
     float a0, b0, a1, b1;  // faces j = 0, 1:  S_0 = a0 + b0 * t,  S_1 = a1 + b1 * (t - 1), scaled by the octave's amplitude.  Each pair is a
                            // pure function of (column, lattice row, octave) -- a sample never depends on where its walk started
+    float c, d;            // S_1 - S_0 = c + d * t:  c = (a1 - b1) - a0, d = b1 - b0, derived whenever a face changes
     float ra, rb;          // fractions along the two lane axes (y walk: x, z; z walk: x, y)
     unsigned key;          // y walk: P(X) | P(X+1) << 8 | Z << 16;  z walk: P(P(X+i)+Y+j) for (i,j) = 00, 01, 10, 11, one byte each
 };
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
     __shared__ unsigned s_h2[256];        // byte offsets into s_grad of hash P(i) (low half) and P(i+1) (high half)
     __shared__ v4f s_grad[16];            // gradient of hash h as (gx, gy, gz, 0), components in {-1, 0, 1}
     __shared__ __attribute__((aligned(16))) float s_rows[kColSeg][kRowUsed];   // this segment's rows (96 of their 128 bytes)
+    __shared__ float2 s_uv[NOCT][256];    // fade weights of the two lane axes, per octave and lane: constant along the walk, read back at a face rebuild
 
     const int tid = threadIdx.x;
     unsigned r = blockIdx.x;
@@ -201,9 +203,8 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
         if (tid < 16) {
             const int h = tid;   // gradf(): u = h<8 ? x : y;  v = h<4 ? y : (h==12||h==14 ? x : z);  (h&1 ? -u : u) + (h&2 ? -v : v)
             const float su = (h & 1) ? -1.f : 1.f, sv = (h & 2) ? -1.f : 1.f;
-            float g[3] = {0.f, 0.f, 0.f};
-            g[h < 8 ? 0 : 1] += su;
-            g[h < 4 ? 1 : ((h == 12 || h == 14) ? 0 : 2)] += sv;
+            const bool vx = h == 12 || h == 14;
+            const float g[3] = {(h < 8 ? su : 0.f) + (vx ? sv : 0.f), (h >= 8 ? su : 0.f) + (h < 4 ? sv : 0.f), (h >= 4 && !vx) ? sv : 0.f};
             s_grad[h] = v4f{g[0], g[1], g[2], 0.f};
         }
         // the segment's rows: everything that depends on the walk coordinate alone, staged once per workgroup
@@ -257,7 +258,8 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
                 const unsigned q0 = s_p2[((px & 255u) + B) & 255u], q1 = s_p2[((px >> 8) + B) & 255u];
                 st[o].key = q0 | (q1 << 16);
             }
-            st[o].a0 = st[o].b0 = st[o].a1 = st[o].b1 = 0.f;
+            st[o].a0 = st[o].b0 = st[o].a1 = st[o].b1 = st[o].c = st[o].d = 0.f;
+            s_uv[o][tid] = make_float2(fade(st[o].ra), fade(st[o].rb));   // only this lane ever reads its entries back
             amp[o] = am;   // wave-uniform: the compiler keeps these in SGPRs
             pa *= dl.lacunarity;
             pb *= dl.lacunarity;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
     // one face of the cell: the four corners over the lane axes at lattice row Wp of the walk axis,
     // interpolated along A then B.  The inputs pass through an empty asm statement so that nothing
     // derived from them is hoisted out of the walk for all octaves at once (~50 VGPRs otherwise).
-    auto face = [&](const ColOct &s, unsigned Wp, float am, float &alpha, float &beta) {
+    auto face = [&](const ColOct &s, int o, unsigned Wp, float am, float &alpha, float &beta) {
         float ra = s.ra, rb = s.rb;
         unsigned key = s.key;
         asm volatile("" : "+v"(ra), "+v"(rb), "+v"(key));
@@ -289,7 +291,8 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
             g10 = *reinterpret_cast<const v4f *>(gb + (s_h2[(((key >> 16) & 255u) + Wp) & 255u] & 0xFFFFu));
             g11 = *reinterpret_cast<const v4f *>(gb + (s_h2[((key >> 24) + Wp) & 255u] & 0xFFFFu));
         }
-        const float u = fade(ra), v = fade(rb);
+        const float2 uv = s_uv[o][tid];
+        const float u = uv.x, v = uv.y;
         const float a0 = ra, a1 = ra - 1.0f, b0 = rb, b1 = rb - 1.0f;
         // gradient components: A is always x; B is z (y walk) or y (z walk); the walk component is the other one
         auto gB = [](const v4f &g) { return WALK == 1 ? g.z : g.y; };
@@ -304,13 +307,13 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
 
     float *dst = out + vol * dl.sv + (long long)i * dl.sx + (long long)j * dl.sy + (long long)k * dl.sz;
     const long long dst_step = WALK == 1 ? dl.sy : dl.sz;
+    float base_sum = 0.0f;   // sum of the low faces' constants a0 over the octaves, re-added in octave order whenever one of them changes
     for (int jj = 0; jj < w_count; ++jj) {
-        // the step's row: six broadcast reads (every lane the same address)
+        // the step's row: five broadcast reads (every lane the same address)
         const v4f *rp = reinterpret_cast<const v4f *>(s_rows[jj]);
-        const v4f ta = rp[0], tb = rp[1], va = rp[2], vb = rp[3], ua = rp[4], ub = rp[5], ma = rp[6];
+        const v4f ta = rp[0], tb = rp[1], va = rp[2], vb = rp[3], ma = rp[6];
         const float t[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
         const float fv[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-        const float t1[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};
         const unsigned m1 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.y)), m2 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.z));
         if (m1 | m2) {   // some octave enters a new lattice cell at this step (the same for every lane: wave-uniform)
             const unsigned wc[2] = {(unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(ma.w)),
@@ -320,20 +323,26 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
                 if ((m1 | m2) & (1u << o)) {
                     const unsigned W = (wc[o >> 2] >> (8 * (o & 3))) & 255u;
                     if (m2 & (1u << o)) {
-                        face(st[o], W, amp[o], st[o].a0, st[o].b0);
+                        face(st[o], o, W, amp[o], st[o].a0, st[o].b0);
                     } else {   // the high face of the cell just left is the low face of this one, bit for bit
                         st[o].a0 = st[o].a1;
                         st[o].b0 = st[o].b1;
                     }
-                    face(st[o], W + 1u, amp[o], st[o].a1, st[o].b1);
+                    face(st[o], o, W + 1u, amp[o], st[o].a1, st[o].b1);
+                    st[o].c = (st[o].a1 - st[o].b1) - st[o].a0;   // S_1(t) = a1 + b1 (t - 1)
+                    st[o].d = st[o].b1 - st[o].b0;
                 }
             }
+            base_sum = 0.0f;
+#pragma unroll
+            for (int o = 0; o < NOCT; ++o) base_sum += st[o].a0;
         }
-        float sum = 0.0f;
+        // noise_o = S_0 + fade(t) (S_1 - S_0) = a0 + b0 t + fade(t) (c + d t): three fmas per octave on top of the constant part
+        float sum = base_sum;
 #pragma unroll
         for (int o = 0; o < NOCT; ++o) {
-            const float s0 = __builtin_fmaf(st[o].b0, t[o], st[o].a0), s1 = __builtin_fmaf(st[o].b1, t1[o], st[o].a1);
-            sum += __builtin_fmaf(fv[o], s1 - s0, s0);
+            sum = __builtin_fmaf(st[o].b0, t[o], sum);
+            sum = __builtin_fmaf(fv[o], __builtin_fmaf(st[o].d, t[o], st[o].c), sum);
         }
         if (live && (!(dl.ablate & 1) || sum == 1e30f)) *dst = sum - (WALK == 1 ? ma.x : lane_ramp);   // ablate 1: diagnostics, no stores
         dst += dst_step;
