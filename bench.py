@@ -58,7 +58,8 @@ def parse():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: the same 1024^3 world sharded (BASELINE configs[3]) or 512 chunks per rank")
     ap.add_argument("--grid", "--n", dest="n", type=int, default=None, help="cells per axis (reduced sizes for tests)")
     ap.add_argument("--chunk", type=int, default=128, help="cells per axis of a chunk")
-    ap.add_argument("--batch", type=int, default=128, help="stream2048: chunks per double-buffered batch")
+    ap.add_argument("--batch", type=int, default=256, help="stream2048: chunks per double-buffered batch")
+    ap.add_argument("--sampler-wgs", type=int, default=None, help="stream2048: residency cap of the sampler kernel (workgroups per CU; default: the stream's own)")
     ap.add_argument("--kind", default=None, choices=["perlin3d", "fbm8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chunks", type=int, default=32, help="chunks the CPU oracle is timed on")
@@ -311,7 +312,9 @@ def run_grid(args, torch, dist):
                     gathered.copy_(g.to("cuda"))
             ev1.record(stream)
             gathered_host.copy_(gathered, non_blocking=True)
-        T = ex.extract_finish()   # the one stream wait of the step: T, and everything queued behind the extract
+        if world > 1:
+            stream.synchronize()  # the one host wait of the step: the extract, the collective and the copy queued behind it
+        T = ex.extract_finish()   # (N = 1: the wait for the extract's own event)
         offs = None
         if world > 1:
             # rank r holds chunks r, r + N, ...: chunk order = slot-major; every rank's local exclusive scan
@@ -458,7 +461,7 @@ def run_stream(args, torch, dist):
     rank, world, local, backend = init_distributed(args, torch, dist)
     n, c = args.n, args.chunk
     dim = c + 2
-    with ChunkStream(n, c, args.batch, args.kind, n, rank=rank, world_size=world, device=local) as st:
+    with ChunkStream(n, c, args.batch, args.kind, n, rank=rank, world_size=world, device=local, sampler_wgs_per_cu=args.sampler_wgs) as st:
         n_chunks = len(st.origins)
         cells_total = float(n) ** 3
         for _ in range(max(args.warmup, 1)):   # buffers grow to their steady size

@@ -133,9 +133,11 @@ int32_t vtmc_extract_volumes_device(vtmc_ctx *ctx, const vtmc_volume_batch *batc
  * _async queues classify -> scan -> emit on `stream` and returns at once -- {T, nActive} stay in
  * device memory, there is no mid-pipeline read-back (VoxelTerrain.cs:394-395) --; after it the per-
  * volume counts are final on the stream, so vtmc_copy_volume_counts_device / vtmc_allgather_volume_counts
- * may be queued behind it.  vtmc_extract_finish waits for the stream, returns T and -- when the
- * triangle buffer turned out too small and the emit kernel refused to run -- grows it and runs the
- * emit stage again.  Exactly one _finish per _async; no other extract_* in between. */
+ * may be queued behind it.  vtmc_extract_finish waits for THIS extract (an event behind its emit
+ * launch -- not for work the caller queued behind it on the stream: the next batch's sampler, a
+ * collective, copies; a caller that wants those too synchronises its stream), returns T and -- when
+ * the triangle buffer turned out too small and the emit kernel refused to run -- grows it and runs
+ * the emit stage again.  Exactly one _finish per _async; no other extract_* of this context in between. */
 int32_t vtmc_extract_volumes_device_async(vtmc_ctx *ctx, const vtmc_volume_batch *batch, void *stream, uint32_t flags);
 int32_t vtmc_extract_finish(vtmc_ctx *ctx, int64_t *tri_count);
 

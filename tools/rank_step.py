@@ -41,6 +41,7 @@ for W in [1] + [int(a) for a in args or ["2", "4", "8"]]:
             if with_comm:
                 ex.allgather_volume_counts(gathered.data_ptr(), len(org), stream.cuda_stream)
                 gathered_host.copy_(gathered, non_blocking=True)   # as bench.py: behind the collective, before the one wait
+                stream.synchronize()
             return ex.extract_finish()
 
         for _ in range(3):

@@ -368,13 +368,18 @@ hipError_t launch_density(const DensityLaunch &dl, const unsigned char *d_perm, 
         if (n_wgs <= 0 || n_wgs > 0x7fffffffll || n_rows > 0x7fffffffll) return hipErrorInvalidValue;
         hipLaunchKernelGGL(density_row_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, dl, d_origins, walk_z ? 2 : 1,
                            n_steps, seg_len, d_rows);
+        // residency cap (tuning key "density_wgs_per_cu"): unused dynamic LDS leaves wave slots, registers and LDS to the kernels of
+        // another stream -- the extract stages of the previous batch are HBM-bound, this kernel is ALU-bound
+        const size_t lds_static = 22272 + 2048 * (size_t)dl.octaves;
+        const size_t lds_want = dl.wgs_per_cu > 0 && dl.wgs_per_cu < 4 ? (size_t)(160 * 1024 / dl.wgs_per_cu - 1024) : 0;
+        const size_t dyn = lds_want > lds_static ? (lds_want - lds_static) & ~(size_t)255 : 0;
 #define VTMC_COL(N)                                                                                                                   \
     case N:                                                                                                                           \
         if (walk_z)                                                                                                                   \
-            hipLaunchKernelGGL((density_column_kernel<N, 2>), dim3((unsigned)n_wgs), dim3(256), 0, stream, dl, d_perm, d_origins, d_rows, \
+            hipLaunchKernelGGL((density_column_kernel<N, 2>), dim3((unsigned)n_wgs), dim3(256), dyn, stream, dl, d_perm, d_origins, d_rows, \
                                d_out, fast_is_z, (int)n_plane_wgs, n_seg, seg_len);                                                  \
         else                                                                                                                          \
-            hipLaunchKernelGGL((density_column_kernel<N, 1>), dim3((unsigned)n_wgs), dim3(256), 0, stream, dl, d_perm, d_origins, d_rows, \
+            hipLaunchKernelGGL((density_column_kernel<N, 1>), dim3((unsigned)n_wgs), dim3(256), dyn, stream, dl, d_perm, d_origins, d_rows, \
                                d_out, fast_is_z, (int)n_plane_wgs, n_seg, seg_len);                                                  \
         break;
         switch (dl.octaves) {   // the octave count is a template parameter: the eight octaves of a sample are straight-line code

@@ -190,7 +190,9 @@ int extract_finish(vtmc_ctx *ctx, int64_t *tri_count)
         VTMC_HIP(ctx, hipStreamSynchronize(pe.stream));
     } else {
         for (int attempt = 0;; ++attempt) {
-            VTMC_HIP(ctx, hipStreamSynchronize(pe.stream));
+            // the event behind the emit launch, not the whole stream: work queued behind the extract (the next batch's sampler,
+            // a collective, the caller's own copies) keeps running while the host takes this result
+            VTMC_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
             if (ctx->h_totals[8]) {
                 ctx->pending.active = false;
                 return fail(ctx, VTMC_ERR_DEVICE, "scan: a look-back wait timed out (a predecessor tile never published)");
@@ -320,6 +322,7 @@ int32_t vtmc_create(int32_t device, vtmc_ctx **out_ctx)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     for (auto &ev : ctx->ev_fill)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_origins, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipHostMalloc((void **)&ctx->h_totals, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
     memset(ctx->h_totals, 0, 64 * sizeof(uint32_t));
@@ -355,6 +358,8 @@ int32_t vtmc_destroy(vtmc_ctx *ctx)
                       &ctx->comm_send})
         release(*b);
     if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
+    if (ctx->h_origins) (void)hipHostFree(ctx->h_origins);
+    if (ctx->ev_origins) (void)hipEventDestroy(ctx->ev_origins);
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->ev_fill)
@@ -683,6 +688,7 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     else if (k == "classify_ablate") ctx->tune.classify_ablate = value;
     else if (k == "emit_row_masks") ctx->tune.emit_row_masks = value;
     else if (k == "density_ablate") ctx->tune.density_ablate = value;
+    else if (k == "density_wgs_per_cu") ctx->tune.density_wgs_per_cu = value;
     else if (k == "gather_beside") ctx->tune.gather_beside = value;
     else if (k == "classify_wgs_per_cu") ctx->tune.classify_wgs_per_cu = value;
     else if (k == "emit_group_log2") ctx->tune.emit_group_log2 = value < 0 ? 0 : (value > 8 ? 8 : value);
@@ -934,11 +940,22 @@ int32_t vtmc_density_fill_device_async(vtmc_ctx *ctx, const vtmc_density_params 
         VTMC_HIP(ctx, hipStreamSynchronize(st));  // about to reallocate
     if (int rc = ensure(ctx, ctx->origins, sizeof(int32_t) * 3 * (size_t)n_volumes)) return rc;
     if (int rc = ensure(ctx, ctx->yrows, rows_bytes)) return rc;
-    // stream-ordered behind any earlier fill of this context that still reads the previous origins
-    VTMC_HIP(ctx, hipMemcpyAsync(ctx->origins.p, origins, sizeof(int32_t) * 3 * (size_t)n_volumes, hipMemcpyHostToDevice, st));
-    // the caller's array is only borrowed for this call: wait for that small copy (and for nothing queued after it)
-    VTMC_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-    VTMC_HIP(ctx, hipEventSynchronize(ctx->ev[4]));
+    // The caller's array is only borrowed for this call: it is copied into pinned staging and uploaded from there, stream-ordered
+    // behind any earlier fill of this context that still reads the previous origins.  No wait on `st`: a host that pipelines
+    // batches on one stream (streaming.ChunkStream) must be able to queue this fill behind an extract that is still running.
+    const size_t org_bytes = sizeof(int32_t) * 3 * (size_t)n_volumes;
+    if (ctx->origins_upload_pending) VTMC_HIP(ctx, hipEventSynchronize(ctx->ev_origins));   // the previous upload has left the staging words
+    if (ctx->h_origins_bytes < org_bytes) {
+        if (ctx->h_origins) (void)hipHostFree(ctx->h_origins);
+        ctx->h_origins = nullptr;
+        ctx->h_origins_bytes = 0;
+        VTMC_HIP(ctx, hipHostMalloc((void **)&ctx->h_origins, org_bytes, hipHostMallocDefault));
+        ctx->h_origins_bytes = org_bytes;
+    }
+    memcpy(ctx->h_origins, origins, org_bytes);
+    VTMC_HIP(ctx, hipMemcpyAsync(ctx->origins.p, ctx->h_origins, org_bytes, hipMemcpyHostToDevice, st));
+    VTMC_HIP(ctx, hipEventRecord(ctx->ev_origins, st));
+    ctx->origins_upload_pending = true;
     DensityLaunch dl{};
     dl.frequency = params->frequency;
     dl.lacunarity = params->lacunarity;
@@ -955,6 +972,7 @@ int32_t vtmc_density_fill_device_async(vtmc_ctx *ctx, const vtmc_density_params 
     dl.sv = volume_stride;
     dl.n_volumes = n_volumes;
     dl.ablate = ctx->tune.density_ablate;
+    dl.wgs_per_cu = ctx->tune.density_wgs_per_cu;
     VTMC_HIP(ctx, hipEventRecord(ctx->ev_fill[0], st));
     VTMC_HIP(ctx, launch_density(dl, (const unsigned char *)ctx->perm.p, (const int *)ctx->origins.p, (float *)ctx->yrows.p, d_out, st));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev_fill[1], st));

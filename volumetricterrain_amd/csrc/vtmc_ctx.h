@@ -39,6 +39,10 @@ struct vtmc_ctx {
     uint32_t *h_totals_dev = nullptr;  // the same pinned words as the device sees them (the fused scan writes its totals there)
     uint32_t *h_totals = nullptr;  // pinned: the scan's totals ({T sat, nActive, T lo, T hi}, then the vertex scan's), 64 words
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0..3] stage timing, [4] staging copies
+    int32_t *h_origins = nullptr;   // pinned staging of the sampler's chunk origins
+    size_t h_origins_bytes = 0;
+    hipEvent_t ev_origins = nullptr;   // behind the upload from h_origins
+    bool origins_upload_pending = false;
     float stage_ms[4] = {0, 0, 0, 0};
     hipEvent_t ev_fill[2] = {nullptr, nullptr};  // around the last density kernel (vtmc_last_fill_ms)
     bool fill_timed = false;

@@ -62,6 +62,7 @@ struct Tuning {
     int emit_row_masks = 1;   // emit loads only the tile rows next to cells with triangles (masks from classify)
     int emit_group_log2 = 0;  // each wave takes 2^g consecutive active-list entries per round
     int density_ablate = 0;   // diagnostics only: 1 the sampler skips its stores (output invalid)
+    int density_wgs_per_cu = 0;   // residency cap of the column sampler (0: four workgroups per CU); 3 leaves room for a concurrent extract
     int gather_beside = 1;    // 1: the all-gather of a queued extract runs on a second stream beside the emit kernel; 0: behind it
     int emit_spare_wgs = 0;   // workgroups the emit launch leaves free (one per XCD: room for the collective's kernel beside it)
 };
@@ -128,6 +129,7 @@ struct DensityLaunch {
     long long sx, sy, sz, sv;
     int n_volumes;
     int ablate;  // diagnostics only (vtmc_set_tuning "density_ablate"): 1 skip the stores (output invalid)
+    int wgs_per_cu;  // residency cap of the column sampler (0: its own four workgroups per CU)
 };
 // d_rows: density_rows_bytes(n_volumes, dy, dz) bytes of scratch (the per-(volume, step) rows of the column sampler)
 hipError_t launch_density(const DensityLaunch &dl, const unsigned char *d_perm, const int *d_origins,

@@ -1,13 +1,15 @@
 """Double-buffered streaming extraction over a world too large to hold at once (BASELINE config 5:
 2048^3 cells of 8-octave fBm = 34 GB of samples): the chunks a rank owns are generated and
-extracted batch by batch, batch k+1 being sampled on one context / stream while batch k is
-extracted on the other.  New in the build -- the reference caps a world at 1025 samples per axis
+extracted batch by batch.  New in the build -- the reference caps a world at 1025 samples per axis
 (VoxelTerrain.cs:44) and has no streaming of any kind.
 
-Two vtmc contexts, each with its own HIP stream, density buffer and result buffers; a single host
-thread drives both: the fill of the next batch is queued without waiting
-(vtmc_density_fill_device_async), the extract of the current batch blocks until its T is known, so the
-two overlap on the device.  PyTorch only provides the device allocations.
+Two vtmc contexts (density buffer + result buffers each) fed through ONE HIP stream by a single host
+thread that stays a batch ahead: sample(k + 1) and extract(k) are queued
+(vtmc_density_fill_device_async, vtmc_extract_volumes_device_async) before the host takes batch
+k - 1's result (vtmc_extract_finish waits for that extract's own event only), so the device goes
+from kernel to kernel without waiting for the host.  The sampler (ALU-bound) and the extract stages
+(HBM-bound) each want the whole chip: run side by side on two streams they took 4 % LONGER than back to
+back (profiles/r02c), so they are queued back to back.  PyTorch only provides the allocations and the stream.
 """
 import numpy as np
 
@@ -17,7 +19,7 @@ from .extractor import Extractor, density_params
 
 class ChunkStream:
     def __init__(self, world_cells, chunk=128, batch_chunks=64, kind="fbm8", noise_n=None, seed=1337,
-                 rank=0, world_size=1, device=0):
+                 rank=0, world_size=1, device=0, sampler_wgs_per_cu=None):
         import torch
         if isinstance(world_cells, int):
             world_cells = (world_cells,) * 3
@@ -27,8 +29,12 @@ class ChunkStream:
         self.params = density_params(kind, noise_n or self.world[0], seed)
         self.bpv = (chunk // 8) ** 3
         self._ex = [Extractor(device), Extractor(device)]
+        if sampler_wgs_per_cu is not None:   # residency of the (ALU-bound) sampler: what it leaves free, the other stream's extract uses
+            for e in self._ex:
+                e.set_tuning(density_wgs_per_cu=int(sampler_wgs_per_cu))
         with torch.cuda.device(device):
             self._buf = [torch.empty(self.batch * self.dim ** 3, dtype=torch.float32, device="cuda") for _ in range(2)]
+            self._stream = torch.cuda.Stream()
 
     def close(self):
         for e in self._ex:
@@ -50,23 +56,29 @@ class ChunkStream:
     def _fill(self, slot, k):
         d = self.dim
         self._ex[slot].density_fill_device(self.params, self._origins_of(k), (d, d, d), (1, d, d * d), d ** 3,
-                                           self._buf[slot].data_ptr(), None, wait=False)
+                                           self._buf[slot].data_ptr(), self._stream.cuda_stream, wait=False)
 
     def batches(self):
         """Yields (k, origins, T, extractor): the extractor still holds batch k's results (triangles,
-        block offsets, per-chunk counts) until the generator is advanced twice more."""
+        block offsets, per-chunk counts) until the generator is advanced twice more.
+        Stream order: S0 S1 E0 E1 S2 E2 S3 E3 ... (S = sample, E = extract); the host takes E(k - 1) while E(k) runs."""
         nb = self.n_batches()
         if nb == 0:
             return
         d, c = self.dim, self.chunk
         self._fill(0, 0)
-        for k in range(nb):
-            slot = k & 1
-            if k + 1 < nb:
-                self._fill(slot ^ 1, k + 1)   # sampled while batch k is extracted below
-            org = self._origins_of(k)
-            T = self._ex[slot].extract_volumes_device(self._buf[slot].data_ptr(), (c, c, c), (1, d, d * d), len(org), d ** 3)
-            yield k, org, T, self._ex[slot]
+        if nb > 1:
+            self._fill(1, 1)
+        for k in range(nb + 1):
+            if k < nb:
+                self._ex[k & 1].extract_volumes_device_async(self._buf[k & 1].data_ptr(), (c, c, c), (1, d, d * d),
+                                                             len(self._origins_of(k)), d ** 3, self._stream.cuda_stream)
+            if k >= 1:
+                ex = self._ex[(k - 1) & 1]
+                T = ex.extract_finish()                 # batch k - 1 is done; batch k's extract is already queued behind it
+                if k + 1 < nb:
+                    self._fill((k + 1) & 1, k + 1)      # its buffer is free again
+                yield k - 1, self._origins_of(k - 1), T, ex
 
     def run(self):
         """Drains the stream; returns (total triangles, per-chunk {vertices, triangles} in owned-chunk order)."""
