@@ -19,6 +19,7 @@ $T python3 $R/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 $T python3 $R/bench.py --config stream2048 > $OUT/bench_stream2048.json 2> $OUT/bench_stream.err
 VTMC_BENCH_ONE_DEVICE=1 VTMC_BENCH_BACKEND=gloo $T python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29719 $R/bench.py --gpus 2 --steps 20 --warmup 3 > $OUT/bench_2rank_one_device_gloo.json 2> $OUT/bench_2rank.err
 $T python3 $R/tools/rank_step.py 2 4 8 > $OUT/rank_step.txt 2>&1
+$T python3 $R/tools/rank_step.py --comm 8 > $OUT/rank_step_comm.txt 2>&1
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-indexed > $OUT/stats/bench.json 2> $OUT/stats/err.log
 $T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-indexed > $OUT/fetch/bench.json 2> $OUT/fetch/err.log
 $T rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-indexed > $OUT/write/bench.json 2> $OUT/write/err.log

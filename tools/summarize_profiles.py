@@ -39,7 +39,23 @@ def main():
     st = first(os.path.join(src, "stream", "*", "*_kernel_stats.csv"))
     if st:
         shutil.copy(st, os.path.join(dst, "kernel_stats_stream2048.csv"))
-    for name in ("bench_n1.json", "bench_stream2048.json", "bench_2rank_one_device_gloo.json", "rank_step.txt"):
+    # per-kernel averages over the REAL calls: the first extract's emit launch returns at once (buffer too small, finish() grows it
+    # and launches again) and pulls the stats file's plain average down
+    tr = first(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
+    if tr:
+        dur = collections.defaultdict(list)
+        for r in csv.DictReader(open(tr)):
+            dur[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        bench_line = json.loads([ln for ln in open(os.path.join(src, "stats", "bench.json")) if ln.startswith("{")][-1])
+        rows = {}
+        for k, v in dur.items():
+            if k.startswith("vtmc::"):
+                real = [x for x in v if x >= 10000] or v
+                rows[k] = {"calls": len(v), "calls_under_10us": len(v) - len(real), "avg_ms_real_calls": round(sum(real) / len(real) / 1e6, 4)}
+        json.dump({"rocprofv3_kernel_trace": rows, "bench_hip_events_same_run": bench_line.get("kernels"),
+                   "note": "same process: bench.py under rocprofv3 --kernel-trace --stats; the two averages of a kernel must agree"},
+                  open(os.path.join(dst, "kernel_avg_vs_bench_events.json"), "w"), indent=1)
+    for name in ("bench_n1.json", "bench_stream2048.json", "bench_2rank_one_device_gloo.json", "rank_step.txt", "rank_step_comm.txt"):
         f = os.path.join(src, name)
         if os.path.exists(f) and os.path.getsize(f):
             if name.endswith(".json"):   # torchrun's ranks also print connection chatter on stdout: keep the JSON line
