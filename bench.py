@@ -440,7 +440,7 @@ def run_grid(args, torch, dist):
             "kernels": per_kernel,
             "path_roofline": path,
             "allgather_ms": None if world == 1 else {"avg": round(statistics.mean(gather_ms), 4), "max": round(max(gather_ms), 4),
-                                                     "note": "HIP events around the collective on the extract's stream, rank 0"},
+                                                     "note": "rank 0, HIP events on the extract's stream from the end of the emit kernel to the end of the collective: what the collective adds to the step (it runs beside the emit kernel when the chunks are whole scan tiles)"},
             "host_ms_per_step_beyond_kernels": round(ms_per_step - avg["total"], 4),
             "indexed_output": indexed,
             "cpu_baseline": cpu,

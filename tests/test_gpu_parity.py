@@ -144,6 +144,53 @@ def test_queued_extract_regrows_and_equals_blocking(ex, oracle_mod):
     assert e.value.code == -5
 
 
+@pytest.mark.parametrize("dims,n_vol,kind,indexed", [((128, 128, 128), 3, "fbm8", False), ((96, 40, 24), 2, "perlin3d", False),
+                                                    ((200, 16, 8), 3, "fbm8", True), ((64, 64, 64), 1, "perlin3d", True)])
+def test_classify_from_the_samplers_sign_bits(ex, oracle_mod, dims, n_vol, kind, indexed):
+    """tuning key fill_keeps_signs (the streaming driver's setting): the sampler leaves one sign bit per sample and the classify
+    stage of the same buffer reads those instead of the samples.  Counts, offsets and output must be what the sample-reading
+    classify gives -- partial 64-cell segments, rows that are no multiple of 64 bits, both output modes; a fill of another
+    buffer or layout in between must not be mistaken for this one."""
+    import torch
+    import volumetricterrain_amd as vt
+    nx, ny, nz = dims
+    sy, sz = nx + 2, (nx + 2) * (ny + 2)
+    sv = sz * (nz + 2)
+    org = np.array([[37 * i, 5 * i, 11 * i] for i in range(n_vol)], np.int32)
+    prm = vt.density_params(kind, 96)
+
+    def results(e):
+        T = e.extract_volumes_device(d.data_ptr(), dims, (1, sy, sz), n_vol, sv)
+        _, off_ptr, vc_ptr = e.device_results()
+        bpv = (nx // 8) * (ny // 8) * (nz // 8)
+        out = [T, e.copy_u32(off_ptr, n_vol * bpv + 1).copy(), e.copy_u32(vc_ptr, 2 * n_vol).copy()]
+        if indexed:
+            v, i, vo, to = e.read_indexed_mesh()
+            out += [v.tobytes(), i.tobytes()]
+        else:
+            out.append(e.read_triangles()[0].tobytes())
+        return out
+
+    with vt.Extractor(0) as e2:
+        e2.set_output_mode(indexed)
+        d = torch.empty(n_vol * sv, dtype=torch.float32, device="cuda")
+        other = torch.empty(n_vol * sv, dtype=torch.float32, device="cuda")
+        e2.density_fill_device(prm, org, (nx + 2, ny + 2, nz + 2), (1, sy, sz), sv, d.data_ptr())
+        want = results(e2)
+        assert want[0] > 0
+        e2.set_tuning(fill_keeps_signs=1)
+        e2.density_fill_device(prm, org, (nx + 2, ny + 2, nz + 2), (1, sy, sz), sv, d.data_ptr())
+        got = results(e2)
+        assert e2.last_stage_ms()["classify"] > 0
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+        # signs of another buffer: the extract of `d` falls back to reading samples
+        e2.density_fill_device(vt.density_params(kind, 50), org + 3, (nx + 2, ny + 2, nz + 2), (1, sy, sz), sv, other.data_ptr())
+        got = results(e2)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+
+
 def test_capacity_and_range_errors(ex, oracle_mod):
     """VTMC_ERR_CAPACITY: a destination smaller than T (SURVEY 8b "validate capacity >= T");
     VTMC_ERR_TOO_LARGE: more than 2^31-1 triangles -- the scan's total is kept in 64 bits, so a noise

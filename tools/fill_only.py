@@ -15,6 +15,8 @@ d = torch.empty(64 * dim ** 3, dtype=torch.float32, device="cuda")
 prm = vt.density_params(sys.argv[1] if len(sys.argv) > 1 else "fbm8", n)
 if len(sys.argv) > 2:
     ex.set_tuning(density_ablate=int(sys.argv[2]))
+if os.environ.get("VTMC_FILL_SIGNS") == "1":
+    ex.set_tuning(fill_keeps_signs=1)
 ms = []
 for _ in range(6):
     ex.density_fill_device(prm, org, (dim, dim, dim), (1, dim, dim * dim), dim ** 3, d.data_ptr())

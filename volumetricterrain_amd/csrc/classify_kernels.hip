@@ -90,15 +90,17 @@ __global__ __launch_bounds__(256) void classify_blocks_kernel(BlockSpace sp, Dev
 // reduced over 8-lane groups.  Each sample is requested once per brick (9/8 x 9/8 halo re-reads
 // are served by L2).  No per-cell output: cases are recomputed by the emit kernel from its LDS tile.
 // ----------------------------------------------------------------------------------------------
-template <bool WANT_V>
+// FROM_BITS: the signs come from the sampler's sign volume (SignVolume: tuning key "fill_keeps_signs") -- 2 x 8 bytes per row through the
+// scalar unit instead of 260 bytes per row through the vector memory path; the kernel is then instruction-bound.
+template <bool WANT_V, bool FROM_BITS>
 __global__ __launch_bounds__(256, WANT_V ? 3 : 1) void classify_dense_kernel(BlockSpace sp, DeviceTables tb,
                                                               uint32_t *__restrict__ counts,
                                                               uint32_t *__restrict__ vcounts,
                                                               int nsegx, int n_bricks, int n_wgs, int ablate,
-                                                              unsigned long long *__restrict__ scan_ctrl, int n_scan_ctrl)
+                                                              unsigned long long *__restrict__ scan_ctrl, int n_scan_ctrl, SignVolume sg)
 {
     __shared__ unsigned char s_trinum[256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = FROM_BITS ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : threadIdx.x >> 6;
     // the fused scan that follows on the stream finds its ticket counter and tile status words zeroed
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n_scan_ctrl; i += gridDim.x * 256) scan_ctrl[i] = 0ull;
     s_trinum[threadIdx.x] = tb.tri_num[threadIdx.x];
@@ -128,7 +130,13 @@ __global__ __launch_bounds__(256, WANT_V ? 3 : 1) void classify_dense_kernel(Blo
     const float *brick_base = sp.base + v * sp.sv + (8ll * by) * sp.sy + (8ll * bz) * sp.sz;
 
     unsigned vc = 0, rows = 0;
-    unsigned total = classify_brick_column<WANT_V>(sp, s_trinum, brick_base, gx, gxc, xe, lane, ablate, &vc, &rows);
+    unsigned total;
+    if constexpr (FROM_BITS)
+        total = classify_brick_column<WANT_V, true>(sp, s_trinum, brick_base, gx, gxc, xe, lane, ablate, &vc, &rows,
+                                                    sg.words + ((long long)v * sg.dz + 8 * bz) * sg.plane_words, sg.plane_words,
+                                                    segx * 64 + sg.dx * (8 * by), sg.dx);
+    else
+        total = classify_brick_column<WANT_V, false>(sp, s_trinum, brick_base, gx, gxc, xe, lane, ablate, &vc, &rows);
     // 8-lane group sums = per-block counts
     total += __shfl_xor(total, 1);
     total += __shfl_xor(total, 2);
@@ -425,7 +433,7 @@ hipError_t launch_classify_blocks(const BlockSpace &sp, const DeviceTables &tb, 
 
 hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
                                  uint32_t *vcounts_or_null, int ablate, int wgs_per_cu, unsigned long long *scan_ctrl, int n_scan_ctrl,
-                                 hipStream_t stream)
+                                 const SignVolume &signs, hipStream_t stream)
 {
     const int nsegx = (sp.nx + 63) / 64;
     const long long n_vol = sp.n_blocks / sp.bpv;
@@ -435,12 +443,20 @@ hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, u
     // Residency cap: the kernel needs 65 VGPRs and 256 bytes of LDS, so seven workgroups fit a CU -- and the stream runs
     // faster with fewer (each wave already keeps 81 row loads in flight).  Unused dynamic LDS is what caps it.
     const size_t dyn = wgs_per_cu > 0 && wgs_per_cu < 8 ? (size_t)(160 * 1024 / wgs_per_cu - 1024) & ~(size_t)255 : 0;
-    if (vcounts_or_null)
-        hipLaunchKernelGGL((classify_dense_kernel<true>), dim3((unsigned)n_wgs), dim3(256), dyn, stream, sp, tb, counts, vcounts_or_null,
-                           nsegx, (int)n_bricks, (int)n_wgs, ablate, scan_ctrl, n_scan_ctrl);
+    const dim3 g((unsigned)n_wgs), b(256);
+    if (signs.words) {   // instruction-bound variant: no residency cap
+        if (vcounts_or_null)
+            hipLaunchKernelGGL((classify_dense_kernel<true, true>), g, b, 0, stream, sp, tb, counts, vcounts_or_null, nsegx, (int)n_bricks, (int)n_wgs,
+                               ablate, scan_ctrl, n_scan_ctrl, signs);
+        else
+            hipLaunchKernelGGL((classify_dense_kernel<false, true>), g, b, 0, stream, sp, tb, counts, vcounts_or_null, nsegx, (int)n_bricks, (int)n_wgs,
+                               ablate, scan_ctrl, n_scan_ctrl, signs);
+    } else if (vcounts_or_null)
+        hipLaunchKernelGGL((classify_dense_kernel<true, false>), g, b, dyn, stream, sp, tb, counts, vcounts_or_null, nsegx, (int)n_bricks, (int)n_wgs,
+                           ablate, scan_ctrl, n_scan_ctrl, signs);
     else
-        hipLaunchKernelGGL((classify_dense_kernel<false>), dim3((unsigned)n_wgs), dim3(256), dyn, stream, sp, tb, counts, vcounts_or_null,
-                           nsegx, (int)n_bricks, (int)n_wgs, ablate, scan_ctrl, n_scan_ctrl);
+        hipLaunchKernelGGL((classify_dense_kernel<false, false>), g, b, dyn, stream, sp, tb, counts, vcounts_or_null, nsegx, (int)n_bricks, (int)n_wgs,
+                           ablate, scan_ctrl, n_scan_ctrl, signs);
     return hipGetLastError();
 }
 

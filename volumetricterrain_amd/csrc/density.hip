@@ -176,7 +176,7 @@ template <int NOCT, int WALK>
 __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl, const unsigned char *__restrict__ perm,
                                                               const int *__restrict__ origins, const float *__restrict__ rows,
                                                               float *__restrict__ out, int fast_is_z, int n_plane_wgs, int n_seg,
-                                                              int seg_len)
+                                                              int seg_len, unsigned long long *__restrict__ signs)
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     __shared__ unsigned short s_p2[256];  // P(i) | P(i+1) << 8
@@ -307,6 +307,8 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
 
     float *dst = out + vol * dl.sv + (long long)i * dl.sx + (long long)j * dl.sy + (long long)k * dl.sz;
     const long long dst_step = WALK == 1 ? dl.sy : dl.sz;
+    // sign volume: word ((vol * dz + k) * 4 n_plane_wgs + 4 pw + wave), bit = lane: the sign of plane point 256 pw + tid at step k
+    unsigned long long *sign_dst = (WALK == 2 && signs) ? signs + ((long long)vol * dl.dz + w_begin) * (4ll * n_plane_wgs) + 4 * pw + (tid >> 6) : nullptr;
     float base_sum = 0.0f;   // sum of the low faces' constants a0 over the octaves, re-added in octave order whenever one of them changes
     for (int jj = 0; jj < w_count; ++jj) {
         // the step's row: five broadcast reads (every lane the same address)
@@ -344,13 +346,27 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
             sum = __builtin_fmaf(st[o].b0, t[o], sum);
             sum = __builtin_fmaf(fv[o], __builtin_fmaf(st[o].d, t[o], st[o].c), sum);
         }
-        if (live && (!(dl.ablate & 1) || sum == 1e30f)) *dst = sum - (WALK == 1 ? ma.x : lane_ramp);   // ablate 1: diagnostics, no stores
+        const float value = sum - (WALK == 1 ? ma.x : lane_ramp);
+        if (live && (!(dl.ablate & 1) || sum == 1e30f)) *dst = value;   // ablate 1: diagnostics, no stores
         dst += dst_step;
+        if (WALK == 2 && signs) {   // the sign volume (z walk only): one ballot per wave and step -- what the classify stage needs of this sample
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(value > 0.f);   // lanes past the plane's end own bits nobody reads
+            if ((tid & 63) == 0) *sign_dst = m;
+            sign_dst += 4 * n_plane_wgs;
+        }
     }
 }
 
+// d_signs (optional): density_sign_words(dl) 64-bit words, written when the walk is along z (density_writes_signs(dl))
+bool density_writes_signs(const DensityLaunch &dl)
+{
+    return dl.octaves <= 8 && dl.sx == 1 && dl.sy == dl.dx && dl.sz >= (long long)dl.dx * dl.dy;
+}
+int density_sign_plane_words(int dx, int dy) { return 4 * (int)(((long long)dx * dy + 255) / 256); }
+size_t density_sign_words(const DensityLaunch &dl) { return (size_t)dl.n_volumes * dl.dz * density_sign_plane_words(dl.dx, dl.dy) + 2; }
+
 hipError_t launch_density(const DensityLaunch &dl, const unsigned char *d_perm, const int *d_origins,
-                          float *d_rows, float *d_out, hipStream_t stream)
+                          float *d_rows, float *d_out, unsigned long long *d_signs, hipStream_t stream)
 {
     const int fast_is_z = (dl.sz == 1 && dl.sx != 1) ? 1 : 0;
     const int dfast = fast_is_z ? dl.dz : dl.dx;
@@ -377,10 +393,10 @@ hipError_t launch_density(const DensityLaunch &dl, const unsigned char *d_perm, 
     case N:                                                                                                                           \
         if (walk_z)                                                                                                                   \
             hipLaunchKernelGGL((density_column_kernel<N, 2>), dim3((unsigned)n_wgs), dim3(256), dyn, stream, dl, d_perm, d_origins, d_rows, \
-                               d_out, fast_is_z, (int)n_plane_wgs, n_seg, seg_len);                                                  \
+                               d_out, fast_is_z, (int)n_plane_wgs, n_seg, seg_len, d_signs);                                        \
         else                                                                                                                          \
             hipLaunchKernelGGL((density_column_kernel<N, 1>), dim3((unsigned)n_wgs), dim3(256), dyn, stream, dl, d_perm, d_origins, d_rows, \
-                               d_out, fast_is_z, (int)n_plane_wgs, n_seg, seg_len);                                                  \
+                               d_out, fast_is_z, (int)n_plane_wgs, n_seg, seg_len, nullptr);                                         \
         break;
         switch (dl.octaves) {   // the octave count is a template parameter: the eight octaves of a sample are straight-line code
             VTMC_COL(1) VTMC_COL(2) VTMC_COL(3) VTMC_COL(4) VTMC_COL(5) VTMC_COL(6) VTMC_COL(7) VTMC_COL(8)

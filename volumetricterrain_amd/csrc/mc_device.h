@@ -107,11 +107,66 @@ __device__ __forceinline__ unsigned extract9(u64 e0, u64 e1, int r0)
 // *rowmask (optional) receives, for this lane's cell column, the layers that hold a cell with triangles:
 // bits 0-7 over y, bits 8-15 over z.  OR-ed over a block they tell the emit kernel which rows of the
 // block's 10^3 tile it will touch at all.
-template <bool WANT_V = false>
+// FROM_BITS: the samples' signs come from a sign volume (one bit per sample, written by the sampler: density.hip) instead of
+// the samples: per row two wave-uniform 64-bit words (scalar loads) hold the 65 bits of the brick's row; `sign_plane` points at
+// the plane of the brick's first z layer, `p0` is the bit offset of its first row (x0 + dx * y0), `dxs` the row pitch in bits.
+template <bool WANT_V = false, bool FROM_BITS = false>
 __device__ __forceinline__ unsigned classify_brick_column(const BlockSpace &sp, const unsigned char *s_trinum,
                                                           const float *brick_base, int gx, int gxc, int xe, int lane,
-                                                          int ablate = 0, unsigned *vcount = nullptr, unsigned *rowmask = nullptr)
+                                                          int ablate = 0, unsigned *vcount = nullptr, unsigned *rowmask = nullptr,
+                                                          const unsigned long long *sign_plane = nullptr, int plane_words = 0, int p0 = 0,
+                                                          int dxs = 0)
 {
+    unsigned A[9], N[9];
+    unsigned or_all = 0, and_all = 0x1FFu;
+    if constexpr (FROM_BITS) {
+        // lane r holds the 65-bit window of row r = zz * 9 + yy (two 16-byte loads per lane cover the 81 rows): bits x0 .. x0 + 63
+        // in `win`, bit x0 + 64 in `e`
+        auto row_window = [&](int r, unsigned long long &win, bool &e) {
+            const int zz = r / 9, yy = r - 9 * zz;
+            const int bit0 = p0 + yy * dxs;
+            const unsigned long long *q = sign_plane + (long long)zz * plane_words + (bit0 >> 6);
+            const unsigned long long w0 = q[0], w1 = q[1];
+            const int sh = bit0 & 63;
+            win = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+            e = ((w1 >> sh) & 1ull) != 0ull;
+        };
+        unsigned long long win_a, win_b;
+        bool e_a, e_b;
+        row_window(lane, win_a, e_a);
+        row_window(lane + 64 < 81 ? lane + 64 : 80, win_b, e_b);
+        // a brick whose 81 x 65 sign bits are all equal holds no triangle and no welded vertex -- four of five bricks end here
+        const bool none = win_a == 0ull && win_b == 0ull && !e_a && !e_b, all = win_a == ~0ull && win_b == ~0ull && e_a && e_b;
+        if (__builtin_amdgcn_ballot_w64(!none) == 0ull || __builtin_amdgcn_ballot_w64(!all) == 0ull) {
+            if (WANT_V) *vcount = 0;
+            if (rowmask) *rowmask = 0;
+            return 0;
+        }
+        const u64 e0 = __builtin_amdgcn_ballot_w64(e_a);
+        const u64 e1 = __builtin_amdgcn_ballot_w64(e_b);
+        const unsigned a_lo = (unsigned)win_a, a_hi = (unsigned)(win_a >> 32), b_lo = (unsigned)win_b, b_hi = (unsigned)(win_b >> 32);
+#pragma unroll
+        for (int zz = 0; zz < 9; ++zz) {
+            unsigned a = 0;
+#pragma unroll
+            for (int yy = 0; yy < 9; ++yy) {
+                const int r = zz * 9 + yy;   // compile-time: the row's window comes out of lane r by v_readlane
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(r < 64 ? a_lo : b_lo), r & 63);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(r < 64 ? a_hi : b_hi), r & 63);
+                const unsigned long long win = ((unsigned long long)hi << 32) | lo;
+                a |= (unsigned)((win >> lane) & 1ull) << yy;
+            }
+            A[zz] = a;
+        }
+#pragma unroll
+        for (int zz = 0; zz < 9; ++zz) {
+            const unsigned nb = (unsigned)__shfl_down((int)A[zz], 1);
+            const unsigned ne = extract9(e0, e1, zz * 9);
+            N[zz] = lane == 63 ? ne : nb;
+            or_all |= A[zz] | N[zz];
+            and_all &= A[zz] & N[zz];
+        }
+    } else {
     // 81 row loads, lane-contiguous
     float val[9][9];
 #pragma unroll
@@ -135,7 +190,6 @@ __device__ __forceinline__ unsigned classify_brick_column(const BlockSpace &sp, 
         ex1 = brick_base[xe + yy * sp.sy + zz * sp.sz];
     }
 
-    unsigned A[9], N[9];
 #pragma unroll
     for (int zz = 0; zz < 9; ++zz) {
         unsigned a = 0;
@@ -145,7 +199,6 @@ __device__ __forceinline__ unsigned classify_brick_column(const BlockSpace &sp, 
     }
     const u64 e0 = __builtin_amdgcn_ballot_w64(ex0 > 0.f);
     const u64 e1 = __builtin_amdgcn_ballot_w64(ex1 > 0.f);
-    unsigned or_all = 0, and_all = 0x1FFu;
 #pragma unroll
     for (int zz = 0; zz < 9; ++zz) {
         unsigned nb = (unsigned)__shfl_down((int)A[zz], 1);
@@ -153,6 +206,7 @@ __device__ __forceinline__ unsigned classify_brick_column(const BlockSpace &sp, 
         N[zz] = lane == 63 ? ne : nb;
         or_all |= A[zz] | N[zz];
         and_all &= A[zz] & N[zz];
+    }
     }
 
     unsigned total = 0, rows = 0, yacc = 0, vtotal = 0;

@@ -160,7 +160,19 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     unsigned long long *ctrl = (unsigned long long *)ctx->partials.p;
     const int n_ctrl = (int)(ctrl_words * (indexed ? 2 : 1));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
-    if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_vcounts, ctx->tune.classify_ablate, ctx->tune.classify_wgs_per_cu, ctrl, n_ctrl, stream));
+    SignVolume sg;   // classify from the sampler's sign bits when they describe exactly this buffer (the caller vouches it is unmodified)
+    {
+        const auto &so = ctx->sign_of;
+        if (dense && ctx->tune.fill_keeps_signs && so.valid && sp.base == so.d_out && sp.sy == so.dx && sp.sz == (long long)so.dx * so.dy &&
+            sp.nx == so.dx - 2 && sp.nby * 8 == so.dy - 2 && sp.nbz * 8 == so.dz - 2 && (sp.sv == so.sv || n_volumes <= 1) &&
+            sp.n_blocks / sp.bpv <= so.n_volumes) {
+            sg.words = (const unsigned long long *)ctx->signs.p;
+            sg.plane_words = density_sign_plane_words(so.dx, so.dy);
+            sg.dx = so.dx;
+            sg.dz = so.dz;
+        }
+    }
+    if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_vcounts, ctx->tune.classify_ablate, ctx->tune.classify_wgs_per_cu, ctrl, n_ctrl, sg, stream));
     else VTMC_HIP(ctx, launch_classify_blocks(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_cases, d_vcounts, ctx->n_cus, ctrl, n_ctrl, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
     // one launch: offsets, active list, totals (also straight into the host's pinned words), emit queue cleared; the indexed
@@ -353,7 +365,7 @@ int32_t vtmc_destroy(vtmc_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     comm_release(ctx);
     for (DevBuf *b : {&ctx->d_vert, &ctx->d_trinum, &ctx->counts, &ctx->offsets, &ctx->active, &ctx->partials, &ctx->totals,
-                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->yrows, &ctx->terrain, &ctx->heightmap,
+                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->yrows, &ctx->signs, &ctx->terrain, &ctx->heightmap,
                       &ctx->vcounts, &ctx->voffsets, &ctx->vtotals, &ctx->verts, &ctx->indices, &ctx->chunk_image,
                       &ctx->comm_send})
         release(*b);
@@ -689,6 +701,10 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     else if (k == "emit_row_masks") ctx->tune.emit_row_masks = value;
     else if (k == "density_ablate") ctx->tune.density_ablate = value;
     else if (k == "density_wgs_per_cu") ctx->tune.density_wgs_per_cu = value;
+    else if (k == "fill_keeps_signs") {
+        ctx->tune.fill_keeps_signs = value;
+        ctx->sign_of.valid = false;
+    }
     else if (k == "gather_beside") ctx->tune.gather_beside = value;
     else if (k == "classify_wgs_per_cu") ctx->tune.classify_wgs_per_cu = value;
     else if (k == "emit_group_log2") ctx->tune.emit_group_log2 = value < 0 ? 0 : (value > 8 ? 8 : value);
@@ -973,8 +989,24 @@ int32_t vtmc_density_fill_device_async(vtmc_ctx *ctx, const vtmc_density_params 
     dl.n_volumes = n_volumes;
     dl.ablate = ctx->tune.density_ablate;
     dl.wgs_per_cu = ctx->tune.density_wgs_per_cu;
+    // the samples' sign bits for the classify stage of this same buffer (the streaming driver's setting)
+    unsigned long long *d_signs = nullptr;
+    ctx->sign_of.valid = false;
+    if (ctx->tune.fill_keeps_signs && density_writes_signs(dl)) {
+        const size_t sb = density_sign_words(dl) * sizeof(unsigned long long);
+        if (ctx->signs.bytes < sb) VTMC_HIP(ctx, hipStreamSynchronize(st));  // about to reallocate
+        if (int rc = ensure(ctx, ctx->signs, sb)) return rc;
+        d_signs = (unsigned long long *)ctx->signs.p;
+        ctx->sign_of.valid = true;
+        ctx->sign_of.d_out = d_out;
+        ctx->sign_of.dx = dim_x;
+        ctx->sign_of.dy = dim_y;
+        ctx->sign_of.dz = dim_z;
+        ctx->sign_of.n_volumes = n_volumes;
+        ctx->sign_of.sv = volume_stride;
+    }
     VTMC_HIP(ctx, hipEventRecord(ctx->ev_fill[0], st));
-    VTMC_HIP(ctx, launch_density(dl, (const unsigned char *)ctx->perm.p, (const int *)ctx->origins.p, (float *)ctx->yrows.p, d_out, st));
+    VTMC_HIP(ctx, launch_density(dl, (const unsigned char *)ctx->perm.p, (const int *)ctx->origins.p, (float *)ctx->yrows.p, d_out, d_signs, st));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev_fill[1], st));
     ctx->fill_timed = true;
     return VTMC_OK;

@@ -39,6 +39,13 @@ struct vtmc_ctx {
     uint32_t *h_totals_dev = nullptr;  // the same pinned words as the device sees them (the fused scan writes its totals there)
     uint32_t *h_totals = nullptr;  // pinned: the scan's totals ({T sat, nActive, T lo, T hi}, then the vertex scan's), 64 words
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0..3] stage timing, [4] staging copies
+    VtmcDevBuf signs;               // the sign volume of the last z-walk fill (tuning key "fill_keeps_signs")
+    struct {
+        bool valid = false;
+        const float *d_out = nullptr;
+        int dx = 0, dy = 0, dz = 0, n_volumes = 0;
+        long long sv = 0;
+    } sign_of;                      // which buffer / layout `signs` describes
     int32_t *h_origins = nullptr;   // pinned staging of the sampler's chunk origins
     size_t h_origins_bytes = 0;
     hipEvent_t ev_origins = nullptr;   // behind the upload from h_origins

@@ -50,6 +50,12 @@ struct DeviceTables {
     const unsigned char *tri_num;           // 256 x u8
 };
 
+// The sign volume a z-walk density fill can leave for the classify stage of the same, unmodified buffer (density.hip, "fill_keeps_signs")
+struct SignVolume {
+    const unsigned long long *words = nullptr;   // [(volume * dz + z) * plane_words + (x + dx * y) / 64], bit (x + dx * y) % 64: sample > 0
+    int plane_words = 0, dx = 0, dz = 0;
+};
+
 // A/B knobs (vtmc_set_tuning); defaults are the shipped configuration.
 struct Tuning {
     int emit_fast_math = 1;   // 1: v_rcp/v_rsq (<= ~5e-7 from exact); 0: correctly rounded, bit-compatible with the oracle
@@ -62,6 +68,8 @@ struct Tuning {
     int emit_row_masks = 1;   // emit loads only the tile rows next to cells with triangles (masks from classify)
     int emit_group_log2 = 0;  // each wave takes 2^g consecutive active-list entries per round
     int density_ablate = 0;   // diagnostics only: 1 the sampler skips its stores (output invalid)
+    int fill_keeps_signs = 0;   // 1: a z-walk density fill also leaves the samples' sign bits; an extract of the same, UNMODIFIED buffer by this
+                                // context then classifies from them (1/32 of the bytes) -- the streaming driver's setting
     int density_wgs_per_cu = 0;   // residency cap of the column sampler (0: four workgroups per CU); 3 leaves room for a concurrent extract
     int gather_beside = 1;    // 1: the all-gather of a queued extract runs on a second stream beside the emit kernel; 0: behind it
     int emit_spare_wgs = 0;   // workgroups the emit launch leaves free (one per XCD: room for the collective's kernel beside it)
@@ -79,7 +87,7 @@ hipError_t launch_classify_blocks(const BlockSpace &sp, const DeviceTables &tb, 
                                   int n_scan_ctrl, hipStream_t stream);
 hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
                                  uint32_t *vcounts_or_null, int ablate, int wgs_per_cu, unsigned long long *scan_ctrl, int n_scan_ctrl,
-                                 hipStream_t stream);
+                                 const SignVolume &signs, hipStream_t stream);
 // one-launch scan: ctrl = 2 + n_tiles words zeroed beforehand (ticket, error, tile status); totals[0..3] = {T saturating, nActive,
 // T, 0}, totals[8] = 1 on a look-back time-out, mirrored into host_totals (device-visible pinned memory) when not null;
 // zero_words / n_zero: 32-bit words to clear on the way (the emit kernel's ticket queue)
@@ -133,7 +141,12 @@ struct DensityLaunch {
 };
 // d_rows: density_rows_bytes(n_volumes, dy, dz) bytes of scratch (the per-(volume, step) rows of the column sampler)
 hipError_t launch_density(const DensityLaunch &dl, const unsigned char *d_perm, const int *d_origins,
-                          float *d_rows, float *d_out, hipStream_t stream);
+                          float *d_rows, float *d_out, unsigned long long *d_signs, hipStream_t stream);
+// the sign volume a z-walk fill can leave for the classify stage of the SAME, unmodified buffer (tuning key "fill_keeps_signs")
+bool density_writes_signs(const DensityLaunch &dl);
+int density_sign_plane_words(int dx, int dy);
+size_t density_sign_words(const DensityLaunch &dl);
+
 size_t density_rows_bytes(int n_volumes, int dy, int dz);
 void density_permutation(uint64_t seed, unsigned char perm[256]);
 

@@ -29,6 +29,8 @@ class ChunkStream:
         self.params = density_params(kind, noise_n or self.world[0], seed)
         self.bpv = (chunk // 8) ** 3
         self._ex = [Extractor(device), Extractor(device)]
+        for e in self._ex:   # the sampler leaves the samples' sign bits; the classify stage of the same (unmodified) buffer reads those
+            e.set_tuning(fill_keeps_signs=1)
         if sampler_wgs_per_cu is not None:   # residency of the (ALU-bound) sampler: what it leaves free, the other stream's extract uses
             for e in self._ex:
                 e.set_tuning(density_wgs_per_cu=int(sampler_wgs_per_cu))
