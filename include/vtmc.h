@@ -165,7 +165,12 @@ int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4]);
  * keep results within the parity bar: "emit_fast_math" (1: v_rcp / v_rsq / fma, default; 0: correctly
  * rounded, bit-compatible with the CPU oracle), "emit_wgs_per_cu", "emit_dynamic",
  * "emit_sub_log2", "emit_group_log2", "gather_beside".  "emit_ablate" / "classify_ablate" switch parts of a kernel
- * off for diagnosis and make the output INVALID.  Defaults are the shipped configuration. */
+ * off for diagnosis and make the output INVALID.  Defaults are the shipped configuration.
+ * "fill_keeps_signs" (default 0) is a contract, not a variant: with 1, vtmc_density_fill_device[_async] also leaves
+ * one sign bit per sample in context memory, and an extract by the SAME context of exactly that buffer (pointer,
+ * dims, strides, volume count) classifies from those bits instead of the samples (1/32 of the bytes; results are
+ * identical).  The caller vouches that nothing wrote to the buffer between the fill and the extract; any other
+ * fill by the context, or setting the key again, drops the bits.  streaming.ChunkStream sets it. */
 int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value);
 
 /* Synthetic density sampler (the reference has no noise field of its own):
