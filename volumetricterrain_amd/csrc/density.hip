@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256) void density_generic_kernel(DensityLaunch dl, 
 // twin test: 2e-6).
 // ----------------------------------------------------------------------------------------------
 constexpr int kColSeg = 160;    // steps one workgroup walks before the next segment starts with a two-face rebuild (20 KB of rows in LDS)
-constexpr int kRowUsed = 32;    // dwords of a row the walk reads
-constexpr int kRowDwords = 32;  // [0..7] t, [8..15] fade(t), [16..23] t - 1, 24 ramp (y walk), 25 mask "next cell", 26 mask "rebuild both faces", 27/28 cell & 255 of octaves 0-3 / 4-7
+constexpr int kRowUsed = 24;    // dwords of a row the walk reads
+constexpr int kRowDwords = 24;  // [0..7] t, [8..15] fade(t), 16 ramp (y walk), 17 mask "next cell", 18 mask "rebuild both faces", 19/20 cell & 255 of octaves 0-3 / 4-7
 
 // one thread per (volume, step): the row of everything that depends on the walk coordinate alone
 __global__ __launch_bounds__(256) void density_row_kernel(DensityLaunch dl, const int *__restrict__ origins, int axis, int n_steps,
@@ -146,7 +146,6 @@ __global__ __launch_bounds__(256) void density_row_kernel(DensityLaunch dl, cons
         const float t = y - fy;
         row[o] = t;
         row[8 + o] = fade(t);
-        row[16 + o] = t - 1.0f;
         if (o < dl.octaves) {
             if (j % seg_len == 0 || (cell != prev && cell != prev + 1)) m2 |= 1u << o;   // first step of a walk, or a jump
             else if (cell == prev + 1) m1 |= 1u << o;
@@ -155,12 +154,12 @@ __global__ __launch_bounds__(256) void density_row_kernel(DensityLaunch dl, cons
         y *= dl.lacunarity;
         yp *= dl.lacunarity;
     }
-    row[24] = axis == 1 ? (pw - dl.ramp_center) * dl.ramp_scale : 0.f;
-    row[25] = __uint_as_float(m1);
-    row[26] = __uint_as_float(m2);
-    row[27] = __uint_as_float(yc[0]);
-    row[28] = __uint_as_float(yc[1]);
-    for (int q = 29; q < kRowDwords; ++q) row[q] = 0.f;
+    row[16] = axis == 1 ? (pw - dl.ramp_center) * dl.ramp_scale : 0.f;
+    row[17] = __uint_as_float(m1);
+    row[18] = __uint_as_float(m2);
+    row[19] = __uint_as_float(yc[0]);
+    row[20] = __uint_as_float(yc[1]);
+    for (int q = 21; q < kRowDwords; ++q) row[q] = 0.f;
 }
 
 struct ColOct {
@@ -168,7 +167,8 @@ struct ColOct {
                            // pure function of (column, lattice row, octave) -- a sample never depends on where its walk started
     float c, d;            // S_1 - S_0 = c + d * t:  c = (a1 - b1) - a0, d = b1 - b0, derived whenever a face changes
     float ra, rb;          // fractions along the two lane axes (y walk: x, z; z walk: x, y)
-    unsigned key;          // y walk: P(X) | P(X+1) << 8 | Z << 16;  z walk: P(P(X+i)+Y+j) for (i,j) = 00, 01, 10, 11, one byte each
+    unsigned key;          // y walk: P(X) | P(X+1) << 8 | Z << 16;  z walk: 16 * P(P(X+i)+Y+j) for (i,j) = 00 (low half), 01 (high half)
+    unsigned key2;         // z walk: the same for (i,j) = 10, 11 -- byte offsets into s_g512 before the lattice row is added
 };
 
 // WALK = 1: along y, lane plane (x, z) or (z, x);  WALK = 2: along z, lane plane (x, y)
@@ -180,9 +180,10 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     __shared__ unsigned short s_p2[256];  // P(i) | P(i+1) << 8
-    __shared__ unsigned s_h2[256];        // byte offsets into s_grad of hash P(i) (low half) and P(i+1) (high half)
+    __shared__ unsigned s_h2[WALK == 1 ? 256 : 1];   // y walk: byte offsets into s_grad of hash P(i) (low half) and P(i+1) (high half)
     __shared__ v4f s_grad[16];            // gradient of hash h as (gx, gy, gz, 0), components in {-1, 0, 1}
-    __shared__ __attribute__((aligned(16))) float s_rows[kColSeg][kRowUsed];   // this segment's rows (96 of their 128 bytes)
+    __shared__ v4f s_g512[WALK == 2 ? 512 : 1];      // z walk: gradient of hash P(i & 255), i = key byte + lattice row <= 511 -- one lookup per corner, no wrap
+    __shared__ __attribute__((aligned(16))) float s_rows[kColSeg][kRowUsed];   // this segment's rows
     __shared__ float2 s_uv[NOCT][256];    // fade weights of the two lane axes, per octave and lane: constant along the walk, read back at a face rebuild
 
     const int tid = threadIdx.x;
@@ -199,13 +200,18 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
     {   // tables
         const unsigned p0 = perm[tid], p1 = perm[(tid + 1) & 255];
         s_p2[tid] = (unsigned short)(p0 | (p1 << 8));
-        s_h2[tid] = ((p0 & 15u) << 4) | (((p1 & 15u) << 4) << 16);
+        if (WALK == 1) s_h2[tid] = ((p0 & 15u) << 4) | (((p1 & 15u) << 4) << 16);
         if (tid < 16) {
             const int h = tid;   // gradf(): u = h<8 ? x : y;  v = h<4 ? y : (h==12||h==14 ? x : z);  (h&1 ? -u : u) + (h&2 ? -v : v)
             const float su = (h & 1) ? -1.f : 1.f, sv = (h & 2) ? -1.f : 1.f;
             const bool vx = h == 12 || h == 14;
             const float g[3] = {(h < 8 ? su : 0.f) + (vx ? sv : 0.f), (h >= 8 ? su : 0.f) + (h < 4 ? sv : 0.f), (h >= 4 && !vx) ? sv : 0.f};
             s_grad[h] = v4f{g[0], g[1], g[2], 0.f};
+        }
+        if (WALK == 2) {
+            __syncthreads();   // s_grad
+            s_g512[tid] = s_grad[p0 & 15u];
+            s_g512[tid + 256] = s_grad[p0 & 15u];
         }
         // the segment's rows: everything that depends on the walk coordinate alone, staged once per workgroup
         const float *src = rows + ((long long)vol * n_steps + w_begin) * kRowDwords;
@@ -252,11 +258,13 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
             st[o].ra = pa - fa;
             st[o].rb = pb - fb;
             const unsigned px = s_p2[A];   // P(X) | P(X+1) << 8
+            st[o].key2 = 0u;
             if (WALK == 1) {
                 st[o].key = px | (B << 16);
             } else {   // the x-y part of the hash chain is constant along a z walk
                 const unsigned q0 = s_p2[((px & 255u) + B) & 255u], q1 = s_p2[((px >> 8) + B) & 255u];
-                st[o].key = q0 | (q1 << 16);
+                st[o].key = ((q0 & 255u) << 4) | ((q0 >> 8) << 20);
+                st[o].key2 = ((q1 & 255u) << 4) | ((q1 >> 8) << 20);
             }
             st[o].a0 = st[o].b0 = st[o].a1 = st[o].b1 = st[o].c = st[o].d = 0.f;
             s_uv[o][tid] = make_float2(fade(st[o].ra), fade(st[o].rb));   // only this lane ever reads its entries back
@@ -272,8 +280,8 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
     // derived from them is hoisted out of the walk for all octaves at once (~50 VGPRs otherwise).
     auto face = [&](const ColOct &s, int o, unsigned Wp, float am, float &alpha, float &beta) {
         float ra = s.ra, rb = s.rb;
-        unsigned key = s.key;
-        asm volatile("" : "+v"(ra), "+v"(rb), "+v"(key));
+        unsigned key = s.key, key2 = s.key2;
+        asm volatile("" : "+v"(ra), "+v"(rb), "+v"(key), "+v"(key2));
         const char *gb = reinterpret_cast<const char *>(s_grad);
         v4f g00, g01, g10, g11;   // g[a-corner][b-corner]
         if (WALK == 1) {
@@ -286,10 +294,12 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
             g10 = *reinterpret_cast<const v4f *>(gb + (h1 & 0xFFFFu));
             g11 = *reinterpret_cast<const v4f *>(gb + (h1 >> 16));
         } else {
-            g00 = *reinterpret_cast<const v4f *>(gb + (s_h2[((key & 255u) + Wp) & 255u] & 0xFFFFu));
-            g01 = *reinterpret_cast<const v4f *>(gb + (s_h2[(((key >> 8) & 255u) + Wp) & 255u] & 0xFFFFu));
-            g10 = *reinterpret_cast<const v4f *>(gb + (s_h2[(((key >> 16) & 255u) + Wp) & 255u] & 0xFFFFu));
-            g11 = *reinterpret_cast<const v4f *>(gb + (s_h2[((key >> 24) + Wp) & 255u] & 0xFFFFu));
+            const char *g5 = reinterpret_cast<const char *>(s_g512);
+            const unsigned w16 = Wp << 4;   // wave-uniform
+            g00 = *reinterpret_cast<const v4f *>(g5 + ((key & 0xFFFFu) + w16));
+            g01 = *reinterpret_cast<const v4f *>(g5 + ((key >> 16) + w16));
+            g10 = *reinterpret_cast<const v4f *>(g5 + ((key2 & 0xFFFFu) + w16));
+            g11 = *reinterpret_cast<const v4f *>(g5 + ((key2 >> 16) + w16));
         }
         const float2 uv = s_uv[o][tid];
         const float u = uv.x, v = uv.y;
@@ -313,13 +323,13 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
     for (int jj = 0; jj < w_count; ++jj) {
         // the step's row: five broadcast reads (every lane the same address)
         const v4f *rp = reinterpret_cast<const v4f *>(s_rows[jj]);
-        const v4f ta = rp[0], tb = rp[1], va = rp[2], vb = rp[3], ma = rp[6];
+        const v4f ta = rp[0], tb = rp[1], va = rp[2], vb = rp[3], ma = rp[4];
         const float t[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
         const float fv[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
         const unsigned m1 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.y)), m2 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.z));
         if (m1 | m2) {   // some octave enters a new lattice cell at this step (the same for every lane: wave-uniform)
             const unsigned wc[2] = {(unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(ma.w)),
-                                    (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_rows[jj][28]))};
+                                    (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_rows[jj][20]))};
 #pragma unroll
             for (int o = 0; o < NOCT; ++o) {
                 if ((m1 | m2) & (1u << o)) {
