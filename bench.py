@@ -511,10 +511,11 @@ def run_stream(args, torch, dist):
         avg_ms = kern[dom] / nb
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         # the sampler's own bound is the vector ALU.  Instructions per sample, counted in the kernel's ISA: 3 fmas per
-        # octave + 8 for the step (row unpack, store, loop); a face rebuild is 43, at f * lacunarity^o rebuilds per sample and
-        # octave; a step with any rebuild re-adds the octaves' constants.  Reported next to the HBM figure.
+        # octave + 8 for the step (row unpack, store, loop) + 4 for the sign bits the classify stage reads; a face rebuild is 34, at
+        # f * lacunarity^o rebuilds per sample and octave; a step with any rebuild re-adds the octaves' constants.  Reported next
+        # to the HBM figure.
         rates = [min(1.0, st.params.frequency * (st.params.lacunarity ** o)) for o in range(octaves)]
-        lane_ops = samples * (3.0 * octaves + 8.0 + 43.0 * sum(rates) + octaves * max(rates))
+        lane_ops = samples * (3.0 * octaves + 12.0 + 34.0 * sum(rates) + octaves * max(rates))
         out = {
             "metric": "streamed sampler + marching-cubes extraction throughput on a %d^3 %s world (Mvoxels/s)" % (n, args.kind),
             "value": round(cells_total / step_s / 1e6, 1),
