@@ -25,8 +25,9 @@ def last_per_kernel(path, counter):
 
 
 def first(pattern):
-    g = glob.glob(pattern)
-    return g[0] if g else None
+    """The newest match: gpurun merges a re-run of the same tag into the files of the earlier one."""
+    g = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return g[-1] if g else None
 
 
 def main():
