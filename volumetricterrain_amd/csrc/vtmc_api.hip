@@ -186,7 +186,9 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     pe.active = true;
     pe.launched = true;
     ctx->pending = pe;
-    return queue_emit(ctx, false);
+    const int rc = queue_emit(ctx, false);
+    if (rc) ctx->pending = VtmcPending{};   // nothing to finish: ev[3] was never recorded for this extract
+    return rc;
 }
 
 // Completes a queued extract: waits for the stream, reads {T, V} from pinned memory and -- when the
