@@ -2,10 +2,15 @@
 rows), field smoothness, dense batches and block lists, soup and indexed output -- every case against
 the CPU oracle (cases / offsets / indices bit-exact, floats within 1e-5).  Seeds are fixed: a failure
 names its case."""
+import os
+
 import numpy as np
 import pytest
 
 import fields
+
+# VTMC_FUZZ_SEEDS=200 widens the sweep for a one-off hunt (the default keeps the suite short)
+N_SEEDS = int(os.environ.get("VTMC_FUZZ_SEEDS", "12"))
 
 pytestmark = pytest.mark.gpu
 ATOL = 1e-5
@@ -43,7 +48,7 @@ def check(got, want):
         assert np.abs(np.where(nan, 0, got[f]) - np.where(nan, 0, want[f])).max(initial=0.0) <= ATOL
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_grid_soup_and_indexed(ex, oracle_mod, seed):
     rng = np.random.default_rng(1000 + seed)
     n = tuple(int(8 * rng.integers(1, 10)) for _ in range(3))
@@ -72,7 +77,7 @@ def test_random_grid_soup_and_indexed(ex, oracle_mod, seed):
         assert np.abs(np.where(nan, 0, verts[f]) - np.where(nan, 0, overts[f])).max(initial=0.0) <= ATOL
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(max(4, N_SEEDS // 3)))
 def test_random_padded_volume_batches_on_the_device(ex, oracle_mod, seed):
     """Batches of equally shaped volumes with padded row / slab strides handed over as device pointers."""
     import torch
@@ -97,3 +102,39 @@ def test_random_padded_volume_batches_on_the_device(ex, oracle_mod, seed):
     assert ex.extract_volumes_device(d.data_ptr(), n, (1, sy, sz), nv, vs) == len(want)
     got, _ = ex.read_triangles()
     check(got, want)
+
+
+@pytest.mark.parametrize("seed", range(max(4, N_SEEDS // 3)))
+def test_random_sampled_batches_classify_from_sign_bits(ex, oracle_mod, seed):
+    """Device-sampled batches of random shape: the classify stage reading the sampler's sign bits (fill_keeps_signs) and the
+    one reading the samples must leave the same block offsets, per-volume counts and bytes; the block offsets are also
+    checked against the oracle's count pass over the downloaded field."""
+    import torch
+    import volumetricterrain_amd as vt
+    rng = np.random.default_rng(3000 + seed)
+    n = (int(8 * rng.integers(4, 26)), int(8 * rng.integers(1, 7)), int(8 * rng.integers(1, 7)))
+    nv = int(rng.integers(1, 5))
+    dx, dy, dz = n[0] + 2, n[1] + 2, n[2] + 2
+    sv = dx * dy * dz + int(rng.integers(0, 3)) * 64
+    org = rng.integers(-200, 200, size=(nv, 3)).astype(np.int32)
+    prm = vt.density_params("fbm8" if rng.random() < 0.5 else "perlin3d", int(rng.integers(24, 200)))
+    d = torch.empty(nv * sv, dtype=torch.float32, device="cuda")
+    bpv = (n[0] // 8) * (n[1] // 8) * (n[2] // 8)
+    with vt.Extractor(0) as e2:
+        outs = []
+        for keep in (0, 1):
+            e2.set_tuning(fill_keeps_signs=keep)
+            e2.density_fill_device(prm, org, (dx, dy, dz), (1, dx, dx * dy), sv, d.data_ptr())
+            T = e2.extract_volumes_device(d.data_ptr(), n, (1, dx, dx * dy), nv, sv)
+            _, off_ptr, vc_ptr = e2.device_results()
+            outs.append((T, e2.copy_u32(off_ptr, nv * bpv + 1).copy(), e2.copy_u32(vc_ptr, 2 * nv).copy(), e2.read_triangles()[0].tobytes()))
+        assert outs[0][0] == outs[1][0], (seed, n, nv)
+        assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2]) and outs[0][3] == outs[1][3]
+    host = d.cpu().numpy()
+    want = [0]
+    for v in range(nv):
+        g = host[v * sv:v * sv + dx * dy * dz].reshape(dz, dy, dx).transpose(2, 1, 0)
+        _, offs, _ = oracle_mod.extract_grid(np.ascontiguousarray(g), threads=4, count_only=True)
+        base = want[-1]
+        want.extend((np.asarray(offs[1:], np.int64) + base).tolist())
+    assert np.array_equal(outs[1][1].astype(np.int64), np.asarray(want, np.int64)), (seed, n, nv)
