@@ -174,7 +174,7 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     }
     if (dense) VTMC_HIP(ctx, launch_classify_dense(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_vcounts, ctx->tune.classify_ablate, ctx->tune.classify_wgs_per_cu, ctrl, n_ctrl, sg, stream));
     else VTMC_HIP(ctx, launch_classify_blocks(sp, ctx->tables, (uint32_t *)ctx->counts.p, d_cases, d_vcounts, ctx->n_cus, ctrl, n_ctrl, stream));
-    VTMC_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
+    if (ctx->tune.stage_events) VTMC_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
     // one launch: offsets, active list, totals (also straight into the host's pinned words), emit queue cleared; the indexed
     // output's vertex counts ride along, and so do the per-volume counts when every volume is a whole number of scan tiles
     pe.counts_early = n_volumes > 0 && scan_writes_volume_counts(sp.bpv) && (long long)sp.bpv * n_volumes == (long long)B;
@@ -182,7 +182,7 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
                                     (uint32_t *)ctx->totals.p, ctx->h_totals_dev, (uint32_t *)ctx->totals.p + 64, kQueueWords, d_vcounts,
                                     indexed ? (uint32_t *)ctx->voffsets.p : nullptr, indexed ? (uint32_t *)ctx->vtotals.p : nullptr,
                                     pe.counts_early ? (uint32_t *)ctx->volcounts.p : nullptr, sp.bpv, stream));
-    VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
+    if (ctx->tune.stage_events || (ctx->comm && pe.counts_early)) VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
     pe.active = true;
     pe.launched = true;
     ctx->pending = pe;
@@ -235,13 +235,17 @@ int extract_finish(vtmc_ctx *ctx, int64_t *tri_count)
             if (int rc = queue_emit(ctx, true)) return rc;
         }
         float a = 0, b = 0, c = 0;
-        VTMC_HIP(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
-        VTMC_HIP(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
-        VTMC_HIP(ctx, hipEventElapsedTime(&c, ctx->ev[2], ctx->ev[3]));
+        if (ctx->tune.stage_events) {
+            VTMC_HIP(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+            VTMC_HIP(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+            VTMC_HIP(ctx, hipEventElapsedTime(&c, ctx->ev[2], ctx->ev[3]));
+            ctx->stage_ms[3] = a + b + c;
+        } else {
+            VTMC_HIP(ctx, hipEventElapsedTime(&ctx->stage_ms[3], ctx->ev[0], ctx->ev[3]));
+        }
         ctx->stage_ms[0] = a;
         ctx->stage_ms[1] = b;
         ctx->stage_ms[2] = c;
-        ctx->stage_ms[3] = a + b + c;
     }
     ctx->pending.active = false;
     ctx->has_result = true;
@@ -708,6 +712,7 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
         ctx->sign_of.valid = false;
     }
     else if (k == "gather_beside") ctx->tune.gather_beside = value;
+    else if (k == "stage_events") ctx->tune.stage_events = value;
     else if (k == "classify_wgs_per_cu") ctx->tune.classify_wgs_per_cu = value;
     else if (k == "emit_group_log2") ctx->tune.emit_group_log2 = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (k == "emit_wgs_per_cu") ctx->tune.emit_wgs_per_cu = value;

@@ -71,6 +71,7 @@ struct Tuning {
     int fill_keeps_signs = 0;   // 1: a z-walk density fill also leaves the samples' sign bits; an extract of the same, UNMODIFIED buffer by this
                                 // context then classifies from them (1/32 of the bytes) -- the streaming driver's setting
     int density_wgs_per_cu = 0;   // residency cap of the column sampler (0: four workgroups per CU); 3 leaves room for a concurrent extract
+    int stage_events = 1;     // 1: events between the three kernels (vtmc_last_stage_ms per stage); 0: only around the whole step
     int gather_beside = 1;    // 1: the all-gather of a queued extract runs on a second stream beside the emit kernel; 0: behind it
     int emit_spare_wgs = 0;   // workgroups the emit launch leaves free (one per XCD: room for the collective's kernel beside it)
 };
