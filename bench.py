@@ -287,42 +287,56 @@ def run_grid(args, torch, dist):
     sampler_kernel_ms = ex.last_fill_ms()
 
     native = native_comm(ex, rank, world, backend, dist, torch)
+    # rehearsal hook for a one-GPU box: the N > 1 host path (collective, pinned copy, offsets) through a world-of-one communicator
+    force_comm = world == 1 and os.environ.get("VTMC_BENCH_FORCE_COMM") == "1"
+    if force_comm:
+        ex.comm_init_rank(ex.comm_unique_id(), 0, 1)
+        native = True
+    exchange = world > 1 or force_comm
     flags = 2 if args.no_dense else 0
     gathered = torch.zeros((world, per_rank, 2), dtype=torch.int32, device="cuda")
     gathered_host = torch.zeros((world, per_rank, 2), dtype=torch.int32).pin_memory()
+    host_rows = gathered_host.numpy().reshape(-1, 2)           # a view of the pinned words
+    host_bytes = host_rows.nbytes
+    # rank r holds chunks r, r + N, ...: chunk c sits in slot c // N of rank c % N
+    perm = np.array([(ch % world) * per_rank + ch // world for ch in range(n_chunks_total)], np.intp)
+    offs_buf = np.zeros((n_chunks_total + 1, 2), np.int64)
     counts_dev = torch.zeros((per_rank, 2), dtype=torch.int32, device="cuda")
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     stage_acc = {"classify": 0.0, "scan": 0.0, "emit": 0.0, "total": 0.0}
     gather_ms = []
+    d_ptr, g_ptr, h_ptr, s_ptr = d_field.data_ptr(), gathered.data_ptr(), gathered_host.data_ptr(), stream.cuda_stream
 
-    def step(accumulate=False):
+    def step(accumulate=False, timed_gather=False):
         """queue: classify -> scan -> emit [-> all-gather -> copy of the gathered counts]; ONE host wait."""
-        ex.extract_volumes_device_async(d_field.data_ptr(), (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, stream.cuda_stream, flags)
-        if world > 1:
-            ev0.record(stream)
-            if native:     # the path's one collective, behind the C ABI, on the same stream
-                ex.allgather_volume_counts(gathered.data_ptr(), per_rank, stream.cuda_stream)
+        ex.extract_volumes_device_async(d_ptr, (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, s_ptr, flags)
+        if exchange:
+            if timed_gather:
+                ev0.record(stream)
+            if native:     # the path's one collective, behind the C ABI; beside the emit kernel when the chunks are whole scan tiles
+                ex.allgather_volume_counts(g_ptr, per_rank, s_ptr)
             else:
-                ex.copy_volume_counts_device(counts_dev.data_ptr(), per_rank, stream.cuda_stream)
+                ex.copy_volume_counts_device(counts_dev.data_ptr(), per_rank, s_ptr)
                 if backend == "nccl":
                     dist.all_gather_into_tensor(gathered.view(-1), counts_dev.view(-1))
                 else:   # gloo rehearsal: through the host
                     stream.synchronize()
                     g = sharding.allgather_counts(counts_dev.cpu())
                     gathered.copy_(g.to("cuda"))
-            ev1.record(stream)
-            gathered_host.copy_(gathered, non_blocking=True)
-        if world > 1:
-            stream.synchronize()  # the one host wait of the step: the extract, the collective and the copy queued behind it
+            if timed_gather:
+                ev1.record(stream)
+            # the one host wait of the step: copy of the gathered pairs into pinned memory + stream wait (extract, collective, copy)
+            ex.copy_into_host(g_ptr, h_ptr, host_bytes, s_ptr)
         T = ex.extract_finish()   # (N = 1: the wait for the extract's own event)
         offs = None
-        if world > 1:
-            # rank r holds chunks r, r + N, ...: chunk order = slot-major; every rank's local exclusive scan
-            offs = sharding.global_offsets(gathered_host.numpy().transpose(1, 0, 2).reshape(-1, 2)[:n_chunks_total])
+        if exchange:   # every rank's local exclusive scan over the chunks in global order
+            np.cumsum(host_rows[perm], axis=0, dtype=np.int64, out=offs_buf[1:])
+            offs = offs_buf
         if accumulate:
-            for k, v in ex.last_stage_ms().items():
-                stage_acc[k] += v
-            if world > 1:
+            ms = ex.last_stage_ms()
+            for k in stage_acc:
+                stage_acc[k] += ms[k]
+            if timed_gather:
                 gather_ms.append(ev0.elapsed_time(ev1))
         return T, offs
 
@@ -333,14 +347,14 @@ def run_grid(args, torch, dist):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        T, offs = step(accumulate=True)
+    for i in range(args.steps):
+        T, offs = step(accumulate=True, timed_gather=exchange and i % 8 == 0)   # the collective's own events on every eighth step
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed, total_tris = reduce_max_sum(elapsed, T, world, backend, torch, dist)
-    if world > 1:
+    if exchange:
         assert int(offs[-1, 1]) == int(total_tris), "gathered chunk counts do not add up to the ranks' triangle totals"
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -440,8 +454,8 @@ def run_grid(args, torch, dist):
             "roofline": roofline,
             "kernels": per_kernel,
             "path_roofline": path,
-            "allgather_ms": None if world == 1 else {"avg": round(statistics.mean(gather_ms), 4), "max": round(max(gather_ms), 4),
-                                                     "note": "rank 0, HIP events on the extract's stream from the end of the emit kernel to the end of the collective: what the collective adds to the step (it runs beside the emit kernel when the chunks are whole scan tiles)"},
+            "allgather_ms": None if not gather_ms else {"avg": round(statistics.mean(gather_ms), 4), "max": round(max(gather_ms), 4),
+                                                     "note": "rank 0, HIP events on the extract's stream from the end of the emit kernel to the end of the collective: what the collective adds to the step (it runs beside the emit kernel when the chunks are whole scan tiles); sampled on every eighth step"},
             "host_ms_per_step_beyond_kernels": round(ms_per_step - avg["total"], 4),
             "indexed_output": indexed,
             "cpu_baseline": cpu,

@@ -180,6 +180,10 @@ class Extractor:
         self._check(self._L.vtmc_copy_to_host(self._h, d_ptr, _ptr(out), int(nbytes), stream))
         return out
 
+    def copy_into_host(self, d_ptr, host_ptr, nbytes, stream=None):
+        """The same copy into memory the caller owns (an address, e.g. of pinned words): nothing is allocated per call."""
+        self._check(self._L.vtmc_copy_to_host(self._h, d_ptr, ctypes.c_void_p(host_ptr), int(nbytes), stream))
+
     def copy_u32(self, d_ptr, count, stream=None):
         return self.copy_to_host(d_ptr, 4 * int(count), stream).view(np.uint32)
 
