@@ -59,3 +59,12 @@ def test_stream_config_line():
     assert j["value"] > 0 and j["triangles_total"] > 0
     assert j["roofline"]["kernel"] in ("density_column_kernel", "classify_dense_kernel", "emit_kernel")
     assert j["sampler_valu"]["frac"] > 0 and j["overlap_gain"] > 0
+
+
+def test_exchange_path_through_a_world_of_one_communicator():
+    """The N > 1 host path of bench.py on one GPU: the library's RCCL all-gather (world of one), the pinned copy + the one
+    wait through the ABI, offsets from the gathered pairs -- and the triangle total they must add up to (asserted in bench.py)."""
+    j = run([sys.executable, "bench.py", "--grid", "256", "--steps", "9", "--warmup", "1", "--no-cpu-baseline", "--no-indexed"],
+            {"VTMC_BENCH_FORCE_COMM": "1"})
+    assert j["n_gpus"] == 1 and abs(j["triangles_total"] - 2655156) < 2000
+    assert j["allgather_ms"] is not None and j["allgather_ms"]["avg"] >= 0
