@@ -9,7 +9,11 @@ count -> prefix scan / compaction -> fused normals + triangle emit, ending when 
 the world stays 1024^3, chunk c belongs to rank c % N (64 chunks each at N = 8), and the step ends
 with the path's one collective, the RCCL all-gather of per-chunk {vertices, triangles} over xGMI
 (vtmc_allgather_volume_counts, queued on the extract's stream; --scaling weak keeps 512 chunks per
-rank on a 1024 x 1024 x 1024*N world instead).
+rank on a 1024 x 1024 x 1024*N world instead).  Steps are independent passes over the same resident input and
+run two deep by default (--pipeline 2): two contexts take turns and step k + 1 is queued before the host takes
+step k's T and offsets, so the device goes from step to step without waiting for the host -- the way a host that
+extracts frame after frame would drive the library; every step still delivers its T, gather and offsets.  `value`
+is that throughput; the latency of an isolated step is reported next to it (`step_latency_ms`, = --pipeline 1).
 
 --config stream2048 (BASELINE.json configs[4]): a 2048^3-cell fbm8 world (36 GB of samples) streamed
 as double-buffered batches of 128^3 chunks: batch k+1 is sampled while batch k is extracted; one
@@ -64,6 +68,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chunks", type=int, default=32, help="chunks the CPU oracle is timed on")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0: physical cores in this process's CPU share, at most 16 per GPU)")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+                    help="grid1024: steps in flight.  2 (default): two contexts take turns, step k + 1 is queued before the host takes step "
+                         "k's result -- the device never waits for the host; 1: every step ends with its host wait (the latency of an "
+                         "isolated step, also reported as step_latency_ms)")
     ap.add_argument("--no-dense", action="store_true", help="A/B: force the per-block classify kernel")
     ap.add_argument("--no-indexed", action="store_true", help="skip the extra indexed-output steps at N = 1")
     args = ap.parse_args()
@@ -271,7 +279,9 @@ def run_grid(args, torch, dist):
     n_chunks_total = (world_dims[0] // c) * (world_dims[1] // c) * (world_dims[2] // c)
     per_rank = (n_chunks_total + world - 1) // world   # slots per rank in the gathered array (zero-padded)
     bpv = (c // 8) ** 3
-    ex = vt.Extractor(local)
+    depth = args.pipeline
+    exs = [vt.Extractor(local) for _ in range(depth)]   # depth 2: the contexts take turns, each with its own result buffers (and communicator)
+    ex = exs[0]
     # one explicit (non-default) HIP stream for everything: the library's kernels, the all-gather and the
     # copy of the gathered counts are ordered by it
     stream = torch.cuda.Stream()
@@ -286,69 +296,97 @@ def run_grid(args, torch, dist):
     sampler_s = time.perf_counter() - t0
     sampler_kernel_ms = ex.last_fill_ms()
 
-    native = native_comm(ex, rank, world, backend, dist, torch)
+    natives = [native_comm(e, rank, world, backend, dist, torch) for e in exs]
+    native = all(natives)
+    if world > 1 and not native:
+        for e, nat in zip(exs, natives):
+            if nat:
+                e.comm_destroy()
     # rehearsal hook for a one-GPU box: the N > 1 host path (collective, pinned copy, offsets) through a world-of-one communicator
     force_comm = world == 1 and os.environ.get("VTMC_BENCH_FORCE_COMM") == "1"
     if force_comm:
-        ex.comm_init_rank(ex.comm_unique_id(), 0, 1)
+        for e in exs:
+            e.comm_init_rank(e.comm_unique_id(), 0, 1)
         native = True
     exchange = world > 1 or force_comm
     flags = 2 if args.no_dense else 0
-    gathered = torch.zeros((world, per_rank, 2), dtype=torch.int32, device="cuda")
-    gathered_host = torch.zeros((world, per_rank, 2), dtype=torch.int32).pin_memory()
-    host_rows = gathered_host.numpy().reshape(-1, 2)           # a view of the pinned words
-    host_bytes = host_rows.nbytes
     # rank r holds chunks r, r + N, ...: chunk c sits in slot c // N of rank c % N
     perm = np.array([(ch % world) * per_rank + ch // world for ch in range(n_chunks_total)], np.intp)
-    offs_buf = np.zeros((n_chunks_total + 1, 2), np.int64)
     counts_dev = torch.zeros((per_rank, 2), dtype=torch.int32, device="cuda")
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    d_ptr, s_ptr = d_field.data_ptr(), stream.cuda_stream
+
+    class Slot:   # what one step in flight owns besides its context
+        def __init__(self, e):
+            self.ex = e
+            self.gathered = torch.zeros((world, per_rank, 2), dtype=torch.int32, device="cuda")
+            self.gathered_host = torch.zeros((world, per_rank, 2), dtype=torch.int32).pin_memory()
+            self.host_rows = self.gathered_host.numpy().reshape(-1, 2)   # a view of the pinned words
+            self.offs = np.zeros((n_chunks_total + 1, 2), np.int64)
+            self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.copied = torch.cuda.Event()
+            self.timed_gather = False
+
+    slots = [Slot(e) for e in exs]
     stage_acc = {"classify": 0.0, "scan": 0.0, "emit": 0.0, "total": 0.0}
     gather_ms = []
-    d_ptr, g_ptr, h_ptr, s_ptr = d_field.data_ptr(), gathered.data_ptr(), gathered_host.data_ptr(), stream.cuda_stream
 
-    def step(accumulate=False, timed_gather=False):
-        """queue: classify -> scan -> emit [-> all-gather -> copy of the gathered counts]; ONE host wait."""
-        ex.extract_volumes_device_async(d_ptr, (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, s_ptr, flags)
+    def queue(sl, timed_gather=False):
+        """classify -> scan -> emit [-> all-gather -> copy of the gathered pairs into pinned words]; nothing waits."""
+        sl.ex.extract_volumes_device_async(d_ptr, (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, s_ptr, flags)
         if exchange:
+            sl.timed_gather = timed_gather
             if timed_gather:
-                ev0.record(stream)
+                sl.ev0.record(stream)
             if native:     # the path's one collective, behind the C ABI; beside the emit kernel when the chunks are whole scan tiles
-                ex.allgather_volume_counts(g_ptr, per_rank, s_ptr)
+                sl.ex.allgather_volume_counts(sl.gathered.data_ptr(), per_rank, s_ptr)
             else:
-                ex.copy_volume_counts_device(counts_dev.data_ptr(), per_rank, s_ptr)
+                sl.ex.copy_volume_counts_device(counts_dev.data_ptr(), per_rank, s_ptr)
                 if backend == "nccl":
-                    dist.all_gather_into_tensor(gathered.view(-1), counts_dev.view(-1))
+                    dist.all_gather_into_tensor(sl.gathered.view(-1), counts_dev.view(-1))
                 else:   # gloo rehearsal: through the host
                     stream.synchronize()
                     g = sharding.allgather_counts(counts_dev.cpu())
-                    gathered.copy_(g.to("cuda"))
+                    sl.gathered.copy_(g.to("cuda"))
             if timed_gather:
-                ev1.record(stream)
-            # the one host wait of the step: copy of the gathered pairs into pinned memory + stream wait (extract, collective, copy)
-            ex.copy_into_host(g_ptr, h_ptr, host_bytes, s_ptr)
-        T = ex.extract_finish()   # (N = 1: the wait for the extract's own event)
+                sl.ev1.record(stream)
+            sl.gathered_host.copy_(sl.gathered, non_blocking=True)
+            sl.copied.record(stream)
+
+    def complete(sl, accumulate=False):
+        """The one host wait of a step: its gathered pairs are in pinned memory (or, without an exchange, its extract is done)."""
+        if exchange:
+            sl.copied.synchronize()
+        T = sl.ex.extract_finish()
         offs = None
         if exchange:   # every rank's local exclusive scan over the chunks in global order
-            np.cumsum(host_rows[perm], axis=0, dtype=np.int64, out=offs_buf[1:])
-            offs = offs_buf
+            np.cumsum(sl.host_rows[perm], axis=0, dtype=np.int64, out=sl.offs[1:])
+            offs = sl.offs
         if accumulate:
-            ms = ex.last_stage_ms()
+            ms = sl.ex.last_stage_ms()
             for k in stage_acc:
                 stage_acc[k] += ms[k]
-            if timed_gather:
-                gather_ms.append(ev0.elapsed_time(ev1))
+            if exchange and sl.timed_gather:
+                gather_ms.append(sl.ev0.elapsed_time(sl.ev1))
         return T, offs
 
-    n_warm = max(args.warmup, 1)   # at least one: output buffers grow to their size and RCCL builds its channels in the first step
-    for _ in range(n_warm):
-        T, offs = step()
+    def run_steps(k_steps, accumulate):
+        """k_steps steps, `depth` in flight: step i + 1 is queued before the host takes step i."""
+        T = offs = None
+        for i in range(k_steps):
+            queue(slots[i % depth], timed_gather=accumulate and exchange and i % 8 == 0)   # the collective's own events on every eighth step
+            if i >= depth - 1:
+                T, offs = complete(slots[(i - depth + 1) % depth], accumulate)
+        for i in range(max(k_steps - depth + 1, 0), k_steps):
+            T, offs = complete(slots[i % depth], accumulate)
+        return T, offs
+
+    n_warm = max(args.warmup, depth)   # every context once at least: output buffers grow to their size, RCCL builds its channels
+    T, offs = run_steps(n_warm, False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        T, offs = step(accumulate=True, timed_gather=exchange and i % 8 == 0)   # the collective's own events on every eighth step
+    T, offs = run_steps(args.steps, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -358,6 +396,15 @@ def run_grid(args, torch, dist):
         assert int(offs[-1, 1]) == int(total_tris), "gathered chunk counts do not add up to the ranks' triangle totals"
 
     ms_per_step = elapsed / args.steps * 1e3
+    # the latency of an isolated step (queue, one host wait), outside the timed region: what --pipeline 1 measures
+    lat = []
+    for _ in range(10):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        queue(slots[0])
+        complete(slots[0])
+        lat.append((time.perf_counter() - t1) * 1e3)
+    step_latency_ms = statistics.median(lat)
     cells_total = float(world_dims[0]) * world_dims[1] * world_dims[2]
     value = cells_total / (elapsed / args.steps) / 1e6
 
@@ -457,13 +504,16 @@ def run_grid(args, torch, dist):
             "allgather_ms": None if not gather_ms else {"avg": round(statistics.mean(gather_ms), 4), "max": round(max(gather_ms), 4),
                                                      "note": "rank 0, HIP events on the extract's stream from the end of the emit kernel to the end of the collective: what the collective adds to the step (it runs beside the emit kernel when the chunks are whole scan tiles); sampled on every eighth step"},
             "host_ms_per_step_beyond_kernels": round(ms_per_step - avg["total"], 4),
+            "pipeline_depth": depth,
+            "step_latency_ms": round(step_latency_ms, 4),
             "indexed_output": indexed,
             "cpu_baseline": cpu,
             "sampler_s": round(sampler_s, 4),
             "sampler_kernel_ms": round(sampler_kernel_ms, 3),
         }
         print(json.dumps(out))
-    ex.close()
+    for e in exs:
+        e.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -30,6 +30,7 @@ def test_single_gpu_line_carries_roofline_and_reproducible_cpu_leg():
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["kernel"] in ("classify_kernel", "emit_kernel") and 0 < r["frac"] < 1
     assert "traffic_source" in r
+    assert j["pipeline_depth"] == 2 and j["step_latency_ms"] > 0      # throughput with two steps in flight, isolated-step latency beside it
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and len(c["repetitions_mvoxels_per_s"]) == 5
     assert all(s >= 0.5 for s in c["repetition_seconds"])
@@ -68,3 +69,6 @@ def test_exchange_path_through_a_world_of_one_communicator():
             {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j["n_gpus"] == 1 and abs(j["triangles_total"] - 2655156) < 2000
     assert j["allgather_ms"] is not None and j["allgather_ms"]["avg"] >= 0
+    j1 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--pipeline", "1"],
+             {"VTMC_BENCH_FORCE_COMM": "1"})
+    assert j1["pipeline_depth"] == 1 and j1["triangles_total"] == j["triangles_total"]
