@@ -312,13 +312,13 @@ def run_grid(args, torch, dist):
     flags = 2 if args.no_dense else 0
     # rank r holds chunks r, r + N, ...: chunk c sits in slot c // N of rank c % N
     perm = np.array([(ch % world) * per_rank + ch // world for ch in range(n_chunks_total)], np.intp)
-    counts_dev = torch.zeros((per_rank, 2), dtype=torch.int32, device="cuda")
     d_ptr, s_ptr = d_field.data_ptr(), stream.cuda_stream
 
     class Slot:   # what one step in flight owns besides its context
         def __init__(self, e):
             self.ex = e
             self.gathered = torch.zeros((world, per_rank, 2), dtype=torch.int32, device="cuda")
+            self.counts_dev = torch.zeros((per_rank, 2), dtype=torch.int32, device="cuda")   # fallback collective's send buffer
             self.gathered_host = torch.zeros((world, per_rank, 2), dtype=torch.int32).pin_memory()
             self.host_rows = self.gathered_host.numpy().reshape(-1, 2)   # a view of the pinned words
             self.offs = np.zeros((n_chunks_total + 1, 2), np.int64)
@@ -340,12 +340,12 @@ def run_grid(args, torch, dist):
             if native:     # the path's one collective, behind the C ABI; beside the emit kernel when the chunks are whole scan tiles
                 sl.ex.allgather_volume_counts(sl.gathered.data_ptr(), per_rank, s_ptr)
             else:
-                sl.ex.copy_volume_counts_device(counts_dev.data_ptr(), per_rank, s_ptr)
+                sl.ex.copy_volume_counts_device(sl.counts_dev.data_ptr(), per_rank, s_ptr)
                 if backend == "nccl":
-                    dist.all_gather_into_tensor(sl.gathered.view(-1), counts_dev.view(-1))
+                    dist.all_gather_into_tensor(sl.gathered.view(-1), sl.counts_dev.view(-1))
                 else:   # gloo rehearsal: through the host
                     stream.synchronize()
-                    g = sharding.allgather_counts(counts_dev.cpu())
+                    g = sharding.allgather_counts(sl.counts_dev.cpu())
                     sl.gathered.copy_(g.to("cuda"))
             if timed_gather:
                 sl.ev1.record(stream)
