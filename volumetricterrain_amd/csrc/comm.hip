@@ -142,7 +142,7 @@ int32_t vtmc_allgather_volume_counts(vtmc_ctx *ctx, uint32_t *d_all_counts, int3
     // When the scan of a queued extract has already left the counts (whole scan tiles per volume), the
     // collective goes to the context's second stream behind the scan's event and runs BESIDE the emit
     // kernel, which was launched a workgroup per XCD short for it; `stream` then only waits for its end.
-    const bool beside = ctx->pending.active && ctx->pending.launched && ctx->pending.counts_early && ctx->tune.gather_beside;
+    const bool beside = ctx->pending.active && ctx->pending.launched && ctx->pending.counts_early && ctx->pending.scan_event && ctx->tune.gather_beside;
     hipStream_t gs = st;
     if (beside) {
         if (!ctx->comm_stream) VTMC_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));

@@ -182,7 +182,10 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
                                     (uint32_t *)ctx->totals.p, ctx->h_totals_dev, (uint32_t *)ctx->totals.p + 64, kQueueWords, d_vcounts,
                                     indexed ? (uint32_t *)ctx->voffsets.p : nullptr, indexed ? (uint32_t *)ctx->vtotals.p : nullptr,
                                     pe.counts_early ? (uint32_t *)ctx->volcounts.p : nullptr, sp.bpv, stream));
-    if (ctx->tune.stage_events || (ctx->comm && pe.counts_early)) VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
+    if (ctx->tune.stage_events || (ctx->comm && pe.counts_early)) {
+        VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
+        pe.scan_event = true;
+    }
     pe.active = true;
     pe.launched = true;
     ctx->pending = pe;

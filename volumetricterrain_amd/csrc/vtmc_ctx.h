@@ -22,6 +22,7 @@ struct VtmcPending {
     bool indexed = false;
     hipStream_t stream = nullptr;
     size_t tcap = 0, vcap = 0;  // capacities the last emit launch was given
+    bool scan_event = false;    // ev[2] was recorded behind this extract's scan
     bool counts_early = false;  // the per-volume counts were final when ev[2] (end of the scan) was recorded
 };
 
