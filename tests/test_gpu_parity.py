@@ -142,6 +142,14 @@ def test_queued_extract_regrows_and_equals_blocking(ex, oracle_mod):
     with pytest.raises(Exception) as e:      # one finish per queued extract
         ex.extract_finish()
     assert e.value.code == -5
+    try:                                     # without the events between the kernels: same bytes, only the step's total is timed
+        ex.set_tuning(stage_events=0)
+        assert ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 3, dim ** 3) == T0
+        assert ex.read_triangles()[0].tobytes() == want.tobytes()
+        ms = ex.last_stage_ms()
+        assert ms["total"] > 0 and ms["classify"] == 0 and ms["emit"] == 0
+    finally:
+        ex.set_tuning(stage_events=1)
 
 
 @pytest.mark.parametrize("dims,n_vol,kind,indexed", [((128, 128, 128), 3, "fbm8", False), ((96, 40, 24), 2, "perlin3d", False),
