@@ -97,13 +97,20 @@ __global__ __launch_bounds__(256, WANT_V ? 3 : 1) void classify_dense_kernel(Blo
                                                               uint32_t *__restrict__ counts,
                                                               uint32_t *__restrict__ vcounts,
                                                               int nsegx, int n_bricks, int n_wgs, int ablate,
-                                                              unsigned long long *__restrict__ scan_ctrl, int n_scan_ctrl, SignVolume sg)
+                                                              unsigned long long *__restrict__ scan_ctrl, int n_scan_ctrl, SignVolume sg, int lane_is_z)
 {
     __shared__ unsigned char s_trinum[256];
     const int lane = threadIdx.x & 63, wave = FROM_BITS ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : threadIdx.x >> 6;
     // the fused scan that follows on the stream finds its ticket counter and tile status words zeroed
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n_scan_ctrl; i += gridDim.x * 256) scan_ctrl[i] = 0ull;
-    s_trinum[threadIdx.x] = tb.tri_num[threadIdx.x];
+    {
+        // z-fastest grids (the C# float[,,] order): the lane walks z and the plane loop x, i.e. the brick code sees the volume with x and
+        // z exchanged and assembles every case with corner bits 1 <-> 4 and 2 <-> 7 exchanged (corner order CollectTriNum.compute:27-37):
+        // the count table is read through that permutation, everything else it derives is symmetric
+        unsigned cs = threadIdx.x;
+        if (lane_is_z) cs = (cs & 0x69u) | ((cs & 0x02u) << 3) | ((cs & 0x10u) >> 3) | ((cs & 0x04u) << 5) | ((cs & 0x80u) >> 5);
+        s_trinum[threadIdx.x] = tb.tri_num[cs];
+    }
     __syncthreads();
 
     // XCD-aware bijective remap: workgroups b, b+8, b+16.. share an XCD (round-robin dispatch), give
@@ -116,18 +123,25 @@ __global__ __launch_bounds__(256, WANT_V ? 3 : 1) void classify_dense_kernel(Blo
     const int brick = wg * kWavesPerWg + wave;
     if (brick >= n_bricks) return;
 
+    // brick -> (segment along the lane axis, block row y, block index along the plane-loop axis, volume)
     int segx = brick % nsegx;
     int t = brick / nsegx;
     int by = t % sp.nby;
     t /= sp.nby;
-    int bz = t % sp.nbz;
-    int v = t / sp.nbz;
+    const int n_loop = lane_is_z ? sp.nbx : sp.nbz;
+    int bz = t % n_loop;      // z block (x fastest) or x block (z fastest)
+    int v = t / n_loop;
 
-    const int gx = segx * 64 + lane;                     // cell / sample x of this lane
-    const int gxc = gx < sp.nx + 1 ? gx : sp.nx + 1;     // clamp loads inside the volume
+    BlockSpace spv = sp;      // the volume as the brick code addresses it: lane axis, y, plane-loop axis
+    if (lane_is_z) {
+        spv.sz = sp.sx;
+        spv.nx = sp.nbz * 8;
+    }
+    const int gx = segx * 64 + lane;                     // cell / sample index of this lane along the lane axis
+    const int gxc = gx < spv.nx + 1 ? gx : spv.nx + 1;   // clamp loads inside the volume
     int xe = segx * 64 + 64;                             // the 65th column
-    xe = xe < sp.nx + 1 ? xe : sp.nx + 1;
-    const float *brick_base = sp.base + v * sp.sv + (8ll * by) * sp.sy + (8ll * bz) * sp.sz;
+    xe = xe < spv.nx + 1 ? xe : spv.nx + 1;
+    const float *brick_base = sp.base + v * sp.sv + (8ll * by) * sp.sy + (8ll * bz) * spv.sz;
 
     unsigned vc = 0, rows = 0;
     unsigned total;
@@ -136,23 +150,27 @@ __global__ __launch_bounds__(256, WANT_V ? 3 : 1) void classify_dense_kernel(Blo
                                                     sg.words + ((long long)v * sg.dz + 8 * bz) * sg.plane_words, sg.plane_words,
                                                     segx * 64 + sg.dx * (8 * by), sg.dx);
     else
-        total = classify_brick_column<WANT_V, false>(sp, s_trinum, brick_base, gx, gxc, xe, lane, ablate, &vc, &rows);
+        total = classify_brick_column<WANT_V, false>(spv, s_trinum, brick_base, gx, gxc, xe, lane, ablate, &vc, &rows);
+    if (lane_is_z)   // the row mask's upper byte is "z layers with triangles": here the lane's own layer, not the plane loop's
+        rows = (rows & 0xFFu) | ((rows & 0xFFu) ? 0x100u << (lane & 7) : 0u);
     // 8-lane group sums = per-block counts
     total += __shfl_xor(total, 1);
     total += __shfl_xor(total, 2);
     total += __shfl_xor(total, 4);
-    const int bx = segx * 8 + (lane >> 3);
-    const int bid = v * sp.bpv + bx + sp.nbx * (by + sp.nby * bz);
+    const int bl = segx * 8 + (lane >> 3);               // block index along the lane axis
+    const int bx = lane_is_z ? bz : bl, bzz = lane_is_z ? bl : bz;
+    const int bid = v * sp.bpv + bx + sp.nbx * (by + sp.nby * bzz);
+    const bool in_volume = bl < (lane_is_z ? sp.nbz : sp.nbx);
     rows |= (unsigned)__shfl_xor((int)rows, 1);
     rows |= (unsigned)__shfl_xor((int)rows, 2);
     rows |= (unsigned)__shfl_xor((int)rows, 4);
     // a block holds at most 2560 triangles: the count shares its word with the block's row mask
-    if ((lane & 7) == 0 && bx < sp.nbx) counts[bid] = total | (rows << 16);
+    if ((lane & 7) == 0 && in_volume) counts[bid] = total | (rows << 16);
     if (WANT_V) {
         vc += __shfl_xor(vc, 1);
         vc += __shfl_xor(vc, 2);
         vc += __shfl_xor(vc, 4);
-        if ((lane & 7) == 0 && bx < sp.nbx) vcounts[bid] = vc;
+        if ((lane & 7) == 0 && in_volume) vcounts[bid] = vc;
     }
 }
 
@@ -435,28 +453,31 @@ hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, u
                                  uint32_t *vcounts_or_null, int ablate, int wgs_per_cu, unsigned long long *scan_ctrl, int n_scan_ctrl,
                                  const SignVolume &signs, hipStream_t stream)
 {
-    const int nsegx = (sp.nx + 63) / 64;
+    // the lane axis is the one with stride 1: x, or z for the C# float[,,] order
+    const int lane_is_z = (sp.sx != 1 && sp.sz == 1) ? 1 : 0;
+    const int n_lane_cells = lane_is_z ? sp.nbz * 8 : sp.nx;
+    const int nsegx = (n_lane_cells + 63) / 64;
     const long long n_vol = sp.n_blocks / sp.bpv;
-    long long n_bricks = n_vol * sp.nbz * sp.nby * nsegx;
+    long long n_bricks = n_vol * (lane_is_z ? sp.nbx : sp.nbz) * sp.nby * nsegx;
     long long n_wgs = (n_bricks + kWavesPerWg - 1) / kWavesPerWg;
     if (n_wgs > 0x7fffffffll) return hipErrorInvalidValue;
     // Residency cap: the kernel needs 65 VGPRs and 256 bytes of LDS, so seven workgroups fit a CU -- and the stream runs
     // faster with fewer (each wave already keeps 81 row loads in flight).  Unused dynamic LDS is what caps it.
     const size_t dyn = wgs_per_cu > 0 && wgs_per_cu < 8 ? (size_t)(160 * 1024 / wgs_per_cu - 1024) & ~(size_t)255 : 0;
     const dim3 g((unsigned)n_wgs), b(256);
-    if (signs.words) {   // instruction-bound variant: no residency cap
+    if (signs.words && !lane_is_z) {   // instruction-bound variant: no residency cap
         if (vcounts_or_null)
             hipLaunchKernelGGL((classify_dense_kernel<true, true>), g, b, 0, stream, sp, tb, counts, vcounts_or_null, nsegx, (int)n_bricks, (int)n_wgs,
-                               ablate, scan_ctrl, n_scan_ctrl, signs);
+                               ablate, scan_ctrl, n_scan_ctrl, signs, 0);
         else
             hipLaunchKernelGGL((classify_dense_kernel<false, true>), g, b, 0, stream, sp, tb, counts, vcounts_or_null, nsegx, (int)n_bricks, (int)n_wgs,
-                               ablate, scan_ctrl, n_scan_ctrl, signs);
+                               ablate, scan_ctrl, n_scan_ctrl, signs, 0);
     } else if (vcounts_or_null)
         hipLaunchKernelGGL((classify_dense_kernel<true, false>), g, b, dyn, stream, sp, tb, counts, vcounts_or_null, nsegx, (int)n_bricks, (int)n_wgs,
-                           ablate, scan_ctrl, n_scan_ctrl, signs);
+                           ablate, scan_ctrl, n_scan_ctrl, signs, lane_is_z);
     else
         hipLaunchKernelGGL((classify_dense_kernel<false, false>), g, b, dyn, stream, sp, tb, counts, vcounts_or_null, nsegx, (int)n_bricks, (int)n_wgs,
-                           ablate, scan_ctrl, n_scan_ctrl, signs);
+                           ablate, scan_ctrl, n_scan_ctrl, signs, lane_is_z);
     return hipGetLastError();
 }
 

@@ -154,7 +154,9 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
             if (int rc = ensure(ctx, ctx->indices, sizeof(int32_t) * 3 * ((size_t)1 << 20))) return rc;
         d_vcounts = (uint32_t *)ctx->vcounts.p;
     }
-    const bool dense = !sp.list && sp.sx == 1 && sp.nx >= 32 && !(flags & (VTMC_FLAG_WANT_CASES | VTMC_FLAG_NO_DENSE_PATH));
+    // the streaming classify wants 32+ cells along the stride-1 axis: x, or z for the C# float[,,] order
+    const bool dense = !sp.list && !(flags & (VTMC_FLAG_WANT_CASES | VTMC_FLAG_NO_DENSE_PATH)) &&
+                       ((sp.sx == 1 && sp.nx >= 32) || (sp.sx != 1 && sp.sz == 1 && sp.nbz * 8 >= 32));
 
     ctx->h_totals[8] = 0u;   // the scan's look-back time-out word
     unsigned long long *ctrl = (unsigned long long *)ctx->partials.p;
@@ -163,7 +165,7 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     SignVolume sg;   // classify from the sampler's sign bits when they describe exactly this buffer (the caller vouches it is unmodified)
     {
         const auto &so = ctx->sign_of;
-        if (dense && ctx->tune.fill_keeps_signs && so.valid && sp.base == so.d_out && sp.sy == so.dx && sp.sz == (long long)so.dx * so.dy &&
+        if (dense && sp.sx == 1 && ctx->tune.fill_keeps_signs && so.valid && sp.base == so.d_out && sp.sy == so.dx && sp.sz == (long long)so.dx * so.dy &&
             sp.nx == so.dx - 2 && sp.nby * 8 == so.dy - 2 && sp.nbz * 8 == so.dz - 2 && (sp.sv == so.sv || n_volumes <= 1) &&
             sp.n_blocks / sp.bpv <= so.n_volumes) {
             sg.words = (const unsigned long long *)ctx->signs.p;
