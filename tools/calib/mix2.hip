@@ -1,0 +1,176 @@
+// mix2.hip -- what does the memory system deliver for a read : write mix?  (round 3; VERDICT r02 task 2)
+//
+// Round 2 quoted 4.4-4.9 TB/s for a "3 reads : 7 writes" stream from ONE untuned kernel (calib.hip mix_kernel: 4096 workgroups,
+// one float4 per lane per step, plain stores) and called that the emit kernel's ceiling.  This program sweeps the shapes a tuned
+// streaming kernel can take before any such number is quoted again:
+//   grid      : persistent, k workgroups per CU (k = 1, 2, 4, 8) of 256 threads, each striding the whole buffer
+//   in flight : U float4 loads issued per lane before their uses (U = 1, 2, 4, 8)
+//   stores    : plain | nontemporal
+//   mixes     : copy (1 : 1), read only, write only, r : w = 3 : 7 (the soup emit), 2 : 5, 1 : 3 (closer to the emit kernel after
+//               row masks), and the emit kernel's own shape: 40-byte rows gathered + 76-byte records (19 dwords per lane) written
+// Every variant is timed over `reps` launches with hipEvents; bytes are the algorithmic ones (reads + writes).
+// Output: one JSON object per line.
+//
+//   hipcc -O3 --offload-arch=gfx950 -o mix2 mix2.hip && ./mix2 [GiB of buffer, default 4]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "%s: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                       \
+        }                                                                                  \
+    } while (0)
+
+// Units of (R + W) float4 per lane-step: the lane reads R float4 from `src` and writes W float4 to `dst`, both streams perfectly
+// coalesced (consecutive lanes, consecutive float4).  U units are in flight per lane (loads first, then the stores).
+template <int R, int W, int U, bool NT>
+__global__ __launch_bounds__(256) void mix_kernel(const v4f *__restrict__ src, v4f *__restrict__ dst, long long n_units)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long u0 = (long long)blockIdx.x * 256 + threadIdx.x; u0 < n_units; u0 += stride * U) {
+        v4f acc[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const long long u = u0 + j * stride;
+            acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+            if (u < n_units) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[j] += src[(long long)r * n_units + u];   // R read streams
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const long long u = u0 + j * stride;
+            if (W == 0 && acc[j].x == 1.2345e30f) dst[0] = acc[j];   // read only: keeps the loads alive, never taken
+            if (u < n_units) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    v4f v = acc[j];
+                    v.x += (float)w;
+                    v4f *p = dst + (long long)w * n_units + u;   // W write streams
+                    if (NT) __builtin_nontemporal_store(v, p);
+                    else *p = v;
+                }
+            }
+        }
+    }
+}
+
+// The emit kernel's own traffic shape without its arithmetic: a wave gathers `rows` 40-byte rows (10 lanes each, 5 rows per load
+// instruction, rows at a 520-byte pitch like a 130-sample grid line) and writes `tris` 76-byte records as one contiguous stream of
+// float4 (the staged form).  rows / tris per wave-step = 64 / 128: a tile after row masks and an average block's triangles.
+__global__ __launch_bounds__(256) void emit_shape_kernel(const float *__restrict__ src, long long src_floats, v4f *__restrict__ dst,
+                                                         long long n_steps)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * 256) >> 6;
+    const int lq = lane % 10, rq = lane / 10;
+    for (long long s = wave; s < n_steps; s += n_waves) {
+        // 64 rows = 13 load instructions of 5 rows (50 lanes)
+        const long long base = (s * 8192) % (src_floats - 70000);
+        float v[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) v[i] = rq < 5 ? src[base + (long long)(5 * i + rq) * 130 + lq] : 0.f;
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) a += v[i];
+        // 128 records x 19 dwords = 608 float4 = 9.5 float4 per lane
+        v4f *o = dst + s * 608;
+        const v4f val = {a, a + 1.f, a + 2.f, a + 3.f};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) o[i * 64 + lane] = val;
+        if (lane < 32) o[576 + lane] = val;
+    }
+}
+
+template <int R, int W, int U, bool NT>
+static void run(const char *name, int wgs_per_cu, int n_cus, const v4f *src, v4f *dst, long long n_units, int reps)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int grid = wgs_per_cu * n_cus;
+    hipLaunchKernelGGL((mix_kernel<R, W, U, NT>), dim3(grid), dim3(256), 0, 0, src, dst, n_units);
+    CK(hipDeviceSynchronize());
+    std::vector<float> ms(reps);
+    for (int i = 0; i < reps; ++i) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((mix_kernel<R, W, U, NT>), dim3(grid), dim3(256), 0, 0, src, dst, n_units);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms[i], e0, e1));
+    }
+    std::sort(ms.begin(), ms.end());
+    const double bytes = (double)n_units * 16.0 * (R + W);
+    printf("{\"kernel\": \"%s\", \"reads\": %d, \"writes\": %d, \"in_flight\": %d, \"nt\": %d, \"wgs_per_cu\": %d, \"GB\": %.3f, "
+           "\"ms_med\": %.4f, \"ms_min\": %.4f, \"TBps_med\": %.3f, \"TBps_best\": %.3f}\n",
+           name, R, W, U, (int)NT, wgs_per_cu, bytes / 1e9, ms[reps / 2], ms[0], bytes / ms[reps / 2] / 1e9, bytes / ms[0] / 1e9);
+    fflush(stdout);
+}
+
+int main(int argc, char **argv)
+{
+    const double gib = argc > 1 ? atof(argv[1]) : 4.0;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int n_cus = prop.multiProcessorCount;
+    const long long total_f4 = (long long)(gib * (1ll << 30)) / 16;
+    v4f *buf;
+    CK(hipMalloc(&buf, total_f4 * 16));
+    CK(hipMemset(buf, 0, total_f4 * 16));
+    const int reps = 7;
+#define SWEEP(R, W, NAME)                                                                     \
+    {                                                                                         \
+        const long long n_units = total_f4 / (R + W);                                         \
+        const v4f *src = buf;                                                                 \
+        v4f *dst = buf + (long long)R * n_units;                                              \
+        run<R, W, 1, false>(NAME, 8, n_cus, src, dst, n_units, reps);                         \
+        run<R, W, 2, false>(NAME, 4, n_cus, src, dst, n_units, reps);                         \
+        run<R, W, 4, false>(NAME, 4, n_cus, src, dst, n_units, reps);                         \
+        run<R, W, 4, false>(NAME, 2, n_cus, src, dst, n_units, reps);                         \
+        run<R, W, 8, false>(NAME, 2, n_cus, src, dst, n_units, reps);                         \
+        run<R, W, 8, false>(NAME, 1, n_cus, src, dst, n_units, reps);                         \
+        run<R, W, 4, true>(NAME, 4, n_cus, src, dst, n_units, reps);                          \
+        run<R, W, 8, true>(NAME, 2, n_cus, src, dst, n_units, reps);                          \
+    }
+    SWEEP(1, 1, "copy")
+    SWEEP(1, 0, "read")
+    SWEEP(0, 1, "write")
+    SWEEP(3, 7, "mix3:7")
+    SWEEP(2, 5, "mix2:5")
+    SWEEP(1, 3, "mix1:3")
+    SWEEP(1, 4, "mix1:4")
+    {   // the emit kernel's own shape
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        const long long dst_f4 = total_f4 * 3 / 4, src_floats = (total_f4 - dst_f4) * 4;
+        const long long n_steps = dst_f4 / 608;
+        const float *src = reinterpret_cast<const float *>(buf + dst_f4);
+        for (int per_cu : {2, 4, 8}) {
+            std::vector<float> ms(reps);
+            for (int i = 0; i < reps + 1; ++i) {
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(emit_shape_kernel, dim3(per_cu * n_cus), dim3(256), 0, 0, src, src_floats, buf, n_steps);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                if (i) CK(hipEventElapsedTime(&ms[i - 1], e0, e1));
+            }
+            std::sort(ms.begin(), ms.end());
+            const double bytes = (double)n_steps * (608.0 * 16 + 64 * 40);
+            printf("{\"kernel\": \"emit_shape\", \"wgs_per_cu\": %d, \"GB\": %.3f, \"ms_med\": %.4f, \"TBps_med\": %.3f, \"TBps_best\": %.3f}\n", per_cu,
+                   bytes / 1e9, ms[reps / 2], bytes / ms[reps / 2] / 1e9, bytes / ms[0] / 1e9);
+        }
+    }
+    CK(hipFree(buf));
+    return 0;
+}

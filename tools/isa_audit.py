@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Audit of the asynchronous tile prefetch in the compiled emit kernels (cdna_hip_programming.md, "What hipcc does not do", item 1).
+
+The emit kernels issue their tile loads and ticket atomics from inline asm, so hipcc neither counts nor waits for them
+(emit_kernels.hip: gload_async / ticket_async / wait_vm_at_most).  An asm load's destination register counts as written at
+;;#ASMEND for the compiler: a copy, a spill or a reuse of it before the data has landed would be silent corruption.  This script
+compiles emit_kernels.hip to gfx950 assembly and checks, for every kernel with asm loads, that
+
+  * the destination registers of the asm loads / atomics are touched by nothing but inline asm, the ds_write of the tile into LDS,
+    v_readfirstlane of the ticket and (before the first asm statement) their initialisation;
+  * the kernel has no scratch and no VGPR spills;
+  * inside the main loop the compiler itself emits no `s_waitcnt vmcnt` for the dense path (only the block-list path may).
+
+usage: tools/isa_audit.py [--keep file.s]      exit code 0 = clean
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "volumetricterrain_amd", "csrc", "emit_kernels.hip")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only"]
+
+
+def compile_asm(out):
+    hipcc = "/opt/rocm/bin/hipcc"
+    subprocess.run([hipcc] + FLAGS + ["-o", out, SRC], check=True, stderr=subprocess.DEVNULL)
+
+
+def kernels(text):
+    """-> {mangled name: [lines]} for every kernel body (label .. s_endpgm)"""
+    out, cur, name = {}, None, None
+    for line in text.splitlines():
+        m = re.match(r"^(_ZN4vtmc\w+):", line)
+        if m:
+            name, cur = m.group(1), []
+            continue
+        if cur is not None:
+            cur.append(line)
+            if "s_endpgm" in line:
+                out[name] = cur
+                cur = None
+    return out
+
+
+def regs_of(operand_text):
+    """VGPR numbers an operand string mentions (v5, v[4:7])"""
+    r = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", operand_text):
+        r.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", operand_text):
+        r.add(int(m.group(1)))
+    return r
+
+
+def audit_kernel(name, lines):
+    """Linear walk: a register is `pending` from the asm statement that loads it to the next asm statement that holds an
+    `s_waitcnt vmcnt` (the counted wait sits at the head of the main loop and once more behind it, so the linear order covers
+    a load's whole way round the loop).  Nothing but inline asm may touch a pending register."""
+    problems = []
+    pending = {}
+    n_loads = 0
+    in_asm = False
+    block = []
+    for i, l in enumerate(lines):
+        if "#ASMSTART" in l:
+            in_asm, block = True, []
+            continue
+        if "#ASMEND" in l:
+            in_asm = False
+            if any("s_waitcnt vmcnt" in b for b in block):
+                pending = {}
+            for b in block:
+                m = re.match(r"\s*(global_load_dword|global_atomic_add)\s+v(\d+)\s*,", b)
+                if m:
+                    pending[int(m.group(2))] = i
+                    n_loads += 1
+            continue
+        if in_asm:
+            block.append(l)
+            continue
+        code = l.split(";")[0].strip()
+        if not code or code.endswith(":") or code.startswith("."):
+            continue
+        touched = regs_of(code) & set(pending)
+        if touched:
+            problems.append("%s: line %d touches v%s while its asm load is in flight: %s" % (name[:60], i, sorted(touched), code))
+    problems += sgpr_hazards(name, lines)
+    return (n_loads or None), problems
+
+
+def sgpr_hazards(name, lines):
+    """A VALU-written SGPR (v_readlane / v_readfirstlane / v_cmp ...) needs five wait states before a VMEM instruction reads it;
+    hipcc pads its own instructions, never the inside of an asm string.  For every vector-memory instruction inside an asm
+    statement: no VALU write of one of its SGPR operands within the five preceding wait states (s_nop N counts N + 1)."""
+    problems = []
+    code = []   # (text, in_asm)
+    in_asm = False
+    for l in lines:
+        if "#ASMSTART" in l:
+            in_asm = True
+            continue
+        if "#ASMEND" in l:
+            in_asm = False
+            continue
+        c = l.split(";")[0].strip()
+        if not c or c.endswith(":") or c.startswith("."):
+            continue
+        code.append((c, in_asm))
+
+    def sregs(text):
+        r = set()
+        for m in re.finditer(r"\bs\[(\d+):(\d+)\]", text):
+            r.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bs(\d+)\b", text):
+            r.add(int(m.group(1)))
+        return r
+
+    for i, (c, a) in enumerate(code):
+        if not a or not re.match(r"(global_|buffer_)", c):
+            continue
+        need = sregs(c)
+        states, j = 0, i - 1
+        while j >= 0 and states < 5:
+            cj = code[j][0]
+            op = cj.split()[0]
+            if op == "s_nop":
+                states += int(cj.split()[1]) + 1
+            else:
+                if op.startswith("v_") and sregs(cj.split(",")[0]) & need:
+                    problems.append("%s: %s reads an SGPR written %d wait states earlier by: %s" % (name[:60], c, states, cj))
+                states += 1
+            j -= 1
+    return problems
+
+
+def main():
+    keep = sys.argv[sys.argv.index("--keep") + 1] if "--keep" in sys.argv else None
+    with tempfile.TemporaryDirectory() as d:
+        path = keep or os.path.join(d, "emit.s")
+        compile_asm(path)
+        text = open(path).read()
+    bad = []
+    n_async = 0
+    for name, lines in kernels(text).items():
+        dst, problems = audit_kernel(name, lines)
+        if dst is None:
+            continue
+        n_async += 1
+        bad += problems
+        print("%s: %d asm loads, %d findings" % (name[:70], dst, len(problems)))
+    for m in re.finditer(r"\.name:\s+(\S+)|\.vgpr_spill_count:\s+(\d+)|\.private_segment_fixed_size:\s+(\d+)", text):
+        if m.group(2) and int(m.group(2)):
+            bad.append("VGPR spills: %s" % m.group(0))
+        if m.group(3) and int(m.group(3)):
+            bad.append("scratch in use: %s" % m.group(0))
+    if n_async == 0:
+        bad.append("no kernel with asm loads found")
+    for b in bad:
+        print("FINDING:", b)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

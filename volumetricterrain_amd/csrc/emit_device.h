@@ -106,12 +106,17 @@ __device__ __forceinline__ void normalise(float d[3])
 // Streams the staged dwords [lo, hi) (stream coordinates: stage[i] goes to gal[i], gal 16-byte aligned)
 // with 16-byte non-temporal stores; the < 4 dwords before the first whole quad and after the last go
 // out as single dwords from lanes 0-3 / 4-7.
+// `vm_issued` grows by the number of body store INSTRUCTIONS this call issues for certain (pass p is issued exactly when lane 0 has a
+// quad, i.e. body_lo + 256 p < body_hi): a lower bound of the wave's vector-memory instructions, which the counted wait of the
+// asynchronous tile prefetch needs (emit_kernels.hip, wait_vm_at_most); the two edge stores are left out of it.
 template <int MAX_PASSES = 3>   // 256 dwords per pass: a bound known at compile time keeps the loop's bookkeeping out of the scalar unit
-__device__ __forceinline__ void stream_out_range(const float *stage, float *__restrict__ gal, int lo, int hi, int lane, int ablate)
+__device__ __forceinline__ void stream_out_range(const float *stage, float *__restrict__ gal, int lo, int hi, int lane, int ablate, int &vm_issued)
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const int body_lo = (lo + 3) & ~3, body_hi = hi & ~3;
     if (!(ablate & 1)) {
+        const int n_pass = body_hi > body_lo ? (body_hi - body_lo + 255) >> 8 : 0;
+        vm_issued += n_pass < MAX_PASSES ? n_pass : MAX_PASSES;
 #pragma unroll
         for (int pass = 0; pass < MAX_PASSES; ++pass) {
             const int q4 = body_lo + 4 * lane + 256 * pass;
@@ -129,19 +134,48 @@ __device__ __forceinline__ void stream_out_range(const float *stage, float *__re
     if (on) __builtin_nontemporal_store(stage[idx], gal + idx);
 }
 
+// The 64 records of a batch (lane r holds record r in `rec`; `on`: the lane has one) leave through a staging area
+// of 33, in two rounds.  In stream coordinates (dwords from the 16-byte aligned address below the batch) record r sits
+// at sh + 19 r; round 0 stages records 0..32 and stores every whole quad below 608 + (sh ? 4 : 0), round 1 stages
+// records 32..63 (record 32 again, so the quad that straddles the two halves left complete in round 0) and continues
+// from that quad boundary: no partial stores in mid-batch.  d0 = first global dword of the batch.
+__device__ __forceinline__ void stream_batch76(float *stage, const float (&rec)[18], bool on, int cnt, size_t d0, int block_id,
+                                               float *__restrict__ out, int lane, int ablate, int &vm_issued)
+{
+    const int sh = (int)(d0 & 3);   // staging shift = global misalignment
+    float *gal = out + (d0 - sh);   // 16-byte aligned
+    const int split = 32 * kTriDwords + (sh ? 4 : 0);   // multiple of 4
+    const int end = sh + cnt * kTriDwords;
+    for (int h = 0; h == 0 || cnt > 32 * h; ++h) {   // wave-uniform, at most two rounds
+        VTMC_WAVE_SYNC();
+        const int r = lane - 32 * h;   // record slot in the staging area
+        if (r >= 0 && r < kStageTris && on) {
+            float *dstrec = stage + sh + r * kTriDwords;
+#pragma unroll
+            for (int c = 0; c < 18; ++c) dstrec[c] = rec[c];
+            dstrec[18] = __int_as_float(block_id);
+        }
+        VTMC_WAVE_SYNC();
+        // stream coordinates of this round, and the same relative to the staging area (which starts at 608 h)
+        const int lo = h == 0 ? sh : split, hi = (h == 0 && cnt > 32) ? split : end;
+        const int base = 32 * kTriDwords * h;
+        stream_out_range<3>(stage - base, gal, lo, hi, lane, ablate, vm_issued);
+    }
+    VTMC_WAVE_SYNC();
+}
+
 // One lane per triangle.  Vertex = position along the edge (MarchingCube.compute:128-133: t =
 // -cube[a] / (cube[b] - cube[a]), lerp with v-u = +-1 on the edge axis and 0 on the others) and the
 // trilinear normal fetch of MarchingCube.compute:69-99, which on a lattice edge is a 2-point lerp
 // whose weight comes from the ROUNDED position (c0 = floor(P), c1 = ceil(P), t = P - c0).
 template <bool FAST>
 __device__ __forceinline__ void emit_flush2(EmitLds2 *L, int pending, size_t tri_base, int block_id,
-                                            float *__restrict__ out, int lane, int ablate)
+                                            float *__restrict__ out, int lane, int ablate, int &vm_issued)
 {
     VTMC_WAVE_SYNC();
     for (int s0 = 0; s0 < pending; s0 += 64) {
         const int s = s0 + lane;
         const size_t d0 = (tri_base + (size_t)s0) * kTriDwords;  // first global dword of this batch
-        const int sh = (int)(d0 & 3);                            // staging shift = global misalignment
         float rec[18];
 #pragma unroll
         for (int c = 0; c < 18; ++c) rec[c] = 0.f;
@@ -189,31 +223,8 @@ __device__ __forceinline__ void emit_flush2(EmitLds2 *L, int pending, size_t tri
                 }
             }
         }
-        // The 64 records of the batch leave through a staging area of 33, in two rounds.  In stream
-        // coordinates (dwords from the 16-byte aligned address below the batch) record r sits at
-        // sh + 19 r; round 0 stages records 0..32 and stores every whole quad below 608 + (sh ? 4 : 0),
-        // round 1 stages records 32..63 (record 32 again, so the quad that straddles the two halves left
-        // complete in round 0) and continues from that quad boundary: no partial stores in mid-batch.
         const int cnt = pending - s0 < 64 ? pending - s0 : 64;
-        float *gal = out + (d0 - sh);  // 16-byte aligned
-        const int split = 32 * kTriDwords + (sh ? 4 : 0);   // multiple of 4
-        const int end = sh + cnt * kTriDwords;
-        for (int h = 0; h == 0 || cnt > 32 * h; ++h) {   // wave-uniform, at most two rounds
-            VTMC_WAVE_SYNC();
-            const int r = lane - 32 * h;   // record slot in the staging area
-            if (r >= 0 && r < kStageTris && s < pending && !(ablate & 4)) {
-                float *dstrec = L->stage + sh + r * kTriDwords;
-#pragma unroll
-                for (int c = 0; c < 18; ++c) dstrec[c] = rec[c];
-                dstrec[18] = __int_as_float(block_id);
-            }
-            VTMC_WAVE_SYNC();
-            // stream coordinates of this round, and the same relative to the staging area (which starts at 608 h)
-            const int lo = h == 0 ? sh : split, hi = (h == 0 && cnt > 32) ? split : end;
-            const int base = 32 * kTriDwords * h;
-            stream_out_range<3>(L->stage - base, gal, lo, hi, lane, ablate);
-        }
-        VTMC_WAVE_SYNC();
+        stream_batch76(L->stage, rec, s < pending && !(ablate & 4), cnt, d0, block_id, out, lane, ablate, vm_issued);
     }
 }
 
@@ -259,7 +270,7 @@ __device__ __forceinline__ int compact_active_cells(const float *tile, unsigned 
 template <bool FAST>
 __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_vert, size_t tri_base, int budget,
                                                      int block_id, float *__restrict__ out, int lane, int ablate,
-                                                     unsigned rowmask = 0xFFFFu)
+                                                     unsigned rowmask, int &vm_issued)
 {
     const int n_act = compact_active_cells<true>(L->tile, L->acell, L->cases, lane, rowmask);   // pass 1
     VTMC_WAVE_SYNC();
@@ -269,7 +280,7 @@ __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_v
     for (int c0 = 0; c0 < n_act; c0 += 64) {
         if (pending > kSlotCap - 320) {  // wave-uniform
             const int n_out = pending < budget ? pending : budget;
-            emit_flush2<FAST>(L, n_out, tri_base, block_id, out, lane, ablate);
+            emit_flush2<FAST>(L, n_out, tri_base, block_id, out, lane, ablate, vm_issued);
             tri_base += n_out;
             budget -= n_out;
             pending = 0;
@@ -288,9 +299,203 @@ __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_v
         pending += (int)step_total;
     }
     if (pending > budget) pending = budget;
-    if (pending > 0) emit_flush2<FAST>(L, pending, tri_base, block_id, out, lane, ablate);
+    if (pending > 0) emit_flush2<FAST>(L, pending, tri_base, block_id, out, lane, ablate, vm_issued);
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Soup, vertex-once ("ONCE"): the 76-byte records of the reference, but every mesh vertex of the block is
+// evaluated ONE time.  A triangle lane of emit_flush2 evaluates its three corners itself -- 3T / V = 4.7
+// evaluations per welded vertex, 64 % of the kernel's vector instructions (profiles/r03a) -- here
+//   N : the active cells number the block's vertices (a vertex = a lattice edge with a sign change; its
+//       owner cell is the one whose corner 0 is the edge's low point, or the boundary cell next to a far
+//       face: owned_edges below) and leave, per vertex, a descriptor (low lattice point | axis) in `vlist`
+//       and, per lattice edge, the vertex id in `vtab` (one byte: axis * 729 + x + 9 y + 81 z);
+//   V : one lane per vertex: position and normal (the arithmetic of MarchingCube.compute:128-133 and
+//       :69-99, from the edge's low endpoint as the indexed output does), 24 bytes into `verts`;
+//   T : one lane per triangle: three table look-ups (cube edge -> lattice edge -> vertex id), three
+//       24-byte LDS reads, the record staged over the (now dead) tile and streamed out as before.
+// The vertex of a cube edge the reference walks from its HIGH end (edges 2, 3, 6, 7 of
+// MarchingCube.compute:40-43) differs from the reference's by rounding only (<= ~1e-6 in cell units against
+// the 1e-5 bar; tests/test_gpu_parity.py); emit_fast_math = 0 keeps the bit-compatible kernel.
+// A block with more than kVertCap vertices or more than kSlotCap triangles takes the per-corner path.
+// ----------------------------------------------------------------------------------------------
+// cube edges with a sign change from the case (the reference's cornerToEdgeTable, VoxelTerrain.cs:489-507, as three nibble
+// operations: edges 0-3 / 4-7 are the low / high corner ring xor its rotation, edges 8-11 the two rings xor each other)
+__device__ __forceinline__ unsigned case_edge_mask_fwd(unsigned cs)
+{
+    const unsigned n = cs & 15u, m = cs >> 4;
+    const unsigned rn = (n ^ ((n >> 1) | (n << 3))) & 15u, rm = (m ^ ((m >> 1) | (m << 3))) & 15u;
+    return rn | (rm << 4) | ((n ^ m) << 8);
+}
+constexpr int kVertCap = 192;          // vertices a block may hold in LDS (1024^3 perlin3d: at most 172)
+constexpr int kOnceVertsBytes = kVertCap * 24;
+
+struct __attribute__((aligned(16))) EmitLdsOnce {
+    EmitLds2 c;   // tile | slot | acell | cases | stage: the per-corner path's view.  ONCE: `verts` starts at c.acell (the active
+                  // cells and their cases are dead when the first vertex is written) and the staging area lies over c.tile
+    unsigned char more[kOnceVertsBytes - (int)(sizeof(EmitLds2) - offsetof(EmitLds2, acell)) + kVertCap * 2 + 2192];
+    __device__ __forceinline__ float *verts() { return reinterpret_cast<float *>(c.acell); }
+    __device__ __forceinline__ unsigned short *vlist() { return reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(c.acell) + kOnceVertsBytes); }
+    __device__ __forceinline__ unsigned char *vtab() { return reinterpret_cast<unsigned char *>(c.acell) + kOnceVertsBytes + kVertCap * 2; }
+};
+static_assert(offsetof(EmitLds2, acell) % 16 == 0 && sizeof(EmitLdsOnce) % 16 == 0 && sizeof(EmitLdsOnce) <= 12736, "three workgroups per CU");
+
+// per-workgroup constant tables of the ONCE path
+struct OnceTables {
+    unsigned short emask[256];   // case -> cube edges with a sign change (VoxelTerrain.cs:489-507)
+    unsigned edge[12];           // cube edge -> low point's offset (x | y << 4 | z << 8) | axis << 12 | lattice-edge offset << 16
+    unsigned short ownx[8];      // which coordinates of a cell are 7 -> the far-face edges it owns
+};
+
+__device__ __forceinline__ unsigned once_edge_entry(unsigned e)
+{
+    const unsigned g = (unsigned)(kEdgeGeom >> (5u * e)) & 31u;
+    const unsigned axis = g >> 3, low = g & 7u & ~(1u << axis);
+    const unsigned lx = low & 1u, ly = (low >> 1) & 1u, lz = low >> 2;
+    return lx | (ly << 4) | (lz << 8) | (axis << 12) | ((axis * 729u + lx + 9u * ly + 81u * lz) << 16);
+}
+
+__device__ __forceinline__ void once_tables_init(OnceTables *t, int tid)   // 256 threads
+{
+    t->emask[tid] = (unsigned short)case_edge_mask_fwd((unsigned)tid);
+    if (tid < 12) t->edge[tid] = once_edge_entry((unsigned)tid);
+    if (tid < 8) {
+        const unsigned X = tid & 1, Y = (tid >> 1) & 1, Z = (tid >> 2) & 1;
+        t->ownx[tid] = (unsigned short)((X * 0x202u) | (Y * 0x804u) | (Z * 0x090u) | ((X & Y) * 0x400u) | ((X & Z) * 0x020u) | ((Y & Z) * 0x040u));
+    }
+}
+
+template <bool FAST>
+__device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_vert, const OnceTables *tb, size_t tri_base, int budget,
+                                                int block_id, float *__restrict__ out, int lane, int ablate, unsigned rowmask, int &vm_issued)
+{
+    if (budget > kSlotCap) {   // wave-uniform: more triangles than the slot buffer holds -- the per-corner path with its own flushes
+        emit_block_from_tile<FAST>(&L->c, s_vert, tri_base, budget, block_id, out, lane, ablate, rowmask, vm_issued);
+        return;
+    }
+    const float *tile = L->c.tile;
+    const int n_act = compact_active_cells<true>(tile, L->c.acell, L->c.cases, lane, rowmask);   // pass 1
+    VTMC_WAVE_SYNC();
+    unsigned short *vlist = L->vlist();
+    unsigned char *vtab = L->vtab();
+
+    // N + pass 2, 64 active cells per step: vertex numbering and triangle slots
+    int n_vert = 0, pending = 0;
+    for (int c0 = 0; c0 < n_act; c0 += 64) {
+        const int idx = c0 + lane;
+        const bool valid = idx < n_act;
+        const unsigned cell = valid ? L->c.acell[idx] : 0u;
+        const unsigned cs = valid ? L->c.cases[cell] : 0u;   // case 0: no edges, no triangles
+        const u64 vw = s_vert[cs];
+        const unsigned em = tb->emask[cs];
+        const unsigned cx = cell & 7u, cy = (cell >> 3) & 7u, cz = cell >> 6;
+        const unsigned desc = cx | (cy << 4) | (cz << 8);
+        const unsigned cell9 = cx + 9u * cy + 81u * cz;
+        // the three edges at the cell's corner 0 (cube edges 0, 3, 8 = the x, y, z lattice edges starting there): one ballot each
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const bool has = (em >> (a == 0 ? 0 : (a == 1 ? 3 : 8))) & 1u;
+            const u64 m = __builtin_amdgcn_ballot_w64(has);
+            if (has) {
+                const int id = n_vert + (int)lanes_below(m);
+                if (id < kVertCap) vlist[id] = (unsigned short)(desc | ((unsigned)a << 12));
+                vtab[729 * a + cell9] = (unsigned char)id;
+            }
+            n_vert += __builtin_popcountll(m);
+        }
+        // the far-face edges of a boundary cell: each round takes every lane's next one
+        const unsigned b7 = (unsigned)(cx == 7u) | ((unsigned)(cy == 7u) << 1) | ((unsigned)(cz == 7u) << 2);
+        unsigned ex = em & tb->ownx[b7];
+        for (u64 m = __builtin_amdgcn_ballot_w64(ex != 0u); m != 0ull; m = __builtin_amdgcn_ballot_w64(ex != 0u)) {
+            if (ex) {
+                const unsigned ed = tb->edge[__builtin_ctz(ex)];
+                const int id = n_vert + (int)lanes_below(m);
+                if (id < kVertCap) vlist[id] = (unsigned short)(desc + (ed & 0xFFFFu));
+                vtab[cell9 + (ed >> 16)] = (unsigned char)id;
+                ex &= ex - 1u;
+            }
+            n_vert += __builtin_popcountll(m);
+        }
+        // triangle slots (as emit_block_from_tile)
+        const unsigned n = (unsigned)(vw >> 60);
+        unsigned step_total;
+        const unsigned pre_n = wave_prefix3(n, step_total);
+        unsigned *dst = L->c.slot + pending + pre_n;
+#pragma unroll
+        for (unsigned i = 0; i < 5; ++i)
+            if (i < n) dst[i] = cell | (((unsigned)(vw >> (12 * i)) & 0xFFFu) << 9);
+        pending += (int)step_total;
+    }
+    if (pending > budget) pending = budget;   // never outside the block's slice of the buffer
+    if (n_vert > kVertCap) {   // wave-uniform: the slots are the per-corner path's own
+        if (pending > 0) emit_flush2<FAST>(&L->c, pending, tri_base, block_id, out, lane, ablate, vm_issued);
+        return;
+    }
+    VTMC_WAVE_SYNC();
+
+    // V: one lane per vertex, from the edge's low endpoint
+    float *verts = L->verts();
+    for (int s0 = 0; s0 < n_vert && !(ablate & 4); s0 += 64) {
+        const int s = s0 + lane;
+        if (s < n_vert) {
+            const unsigned d = vlist[s];
+            const int c[3] = {(int)(d & 15u), (int)((d >> 4) & 15u), (int)((d >> 8) & 15u)};
+            const unsigned axis = d >> 12;
+            const int sk = axis == 0 ? 1 : (axis == 1 ? 10 : 100);
+            const int tl = c[0] + 10 * c[1] + 100 * c[2];
+            const float va = tile[tl], vb = tile[tl + sk];
+            // t lies in [0,1] (the endpoints differ in sign class); the 1-ulp v_rcp can land a hair outside: clamp it back
+            const float t = FAST ? __builtin_amdgcn_fmed3f(-va * __builtin_amdgcn_rcpf(vb - va), 0.0f, 1.0f) : (-va) / (vb - va);
+            const float ckf = (float)(axis == 0 ? c[0] : (axis == 1 ? c[1] : c[2]));
+            const float q = ckf + t;
+            const float fq = floorf(q);
+            const float w = q - fq;   // the weight comes from the ROUNDED position (MarchingCube.compute:71-72)
+            float g0[3], g1[3];
+            lattice_gradient(tile, tl + (int)(fq - ckf) * sk, g0);
+            lattice_gradient(tile, tl + (int)(ceilf(q) - ckf) * sk, g1);
+            normalise<FAST>(g0);
+            normalise<FAST>(g1);
+            float *rec = verts + s * 6;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                rec[a] = axis == (unsigned)a ? q : (float)c[a];
+                rec[3 + a] = FAST ? __builtin_fmaf(w, g1[a] - g0[a], g0[a]) : g0[a] + w * (g1[a] - g0[a]);
+            }
+        }
+    }
+    VTMC_WAVE_SYNC();
+
+    // T: one lane per triangle; the staging area lies over the tile, which nobody reads any more
+    float *stage = L->c.tile;
+    for (int s0 = 0; s0 < pending; s0 += 64) {
+        const int s = s0 + lane;
+        float rec[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) rec[k] = 0.f;
+        if (s < pending) {
+            const unsigned sc = L->c.slot[s];
+            const unsigned cell = sc & 511u, trip = sc >> 9;
+            const unsigned cell9 = (cell & 7u) + 9u * ((cell >> 3) & 7u) + 81u * (cell >> 6);
+            // table entries (3i, 3i+2, 3i+1): the winding swap of MarchingCube.compute:147-157
+            const unsigned e[3] = {trip & 15u, (trip >> 8) & 15u, (trip >> 4) & 15u};
+            unsigned vid[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) vid[k] = vtab[cell9 + (tb->edge[e[k]] >> 16)];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float *v = verts + vid[k] * 6u;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    rec[3 * k + a] = v[a];
+                    rec[9 + 3 * k + a] = v[3 + a];
+                }
+            }
+        }
+        const int cnt = pending - s0 < 64 ? pending - s0 : 64;
+        stream_batch76(stage, rec, s < pending, cnt, (tri_base + (size_t)s0) * kTriDwords, block_id, out, lane, ablate, vm_issued);
+    }
+}
 
 // ----------------------------------------------------------------------------------------------
 // Indexed (welded) output of one block -- new in the build (the reference welds later, on the CPU,
@@ -381,7 +586,7 @@ __device__ __forceinline__ unsigned wave_prefix4(unsigned n, unsigned &total)
 // through 33 slots in two rounds split at a 16-byte boundary of the output stream (see emit_flush2).
 template <int REC, int STAGE_DWORDS>
 __device__ __forceinline__ void stream_records(float *stage, const float (&rec)[REC], int cnt, float *__restrict__ out, size_t d0,
-                                               int lane, int ablate)
+                                               int lane, int ablate, int &vm_issued)
 {
     const int sh = (int)(d0 & 3);
     float *gal = out + (d0 - sh);
@@ -393,7 +598,7 @@ __device__ __forceinline__ void stream_records(float *stage, const float (&rec)[
             for (int c = 0; c < REC; ++c) d[c] = rec[c];
         }
         VTMC_WAVE_SYNC();
-        stream_out_range<(64 * REC + 3 + 255) / 256>(stage, gal, sh, sh + cnt * REC, lane, ablate);
+        stream_out_range<(64 * REC + 3 + 255) / 256>(stage, gal, sh, sh + cnt * REC, lane, ablate, vm_issued);
         VTMC_WAVE_SYNC();
         return;
     }
@@ -408,7 +613,7 @@ __device__ __forceinline__ void stream_records(float *stage, const float (&rec)[
         }
         VTMC_WAVE_SYNC();
         const int lo = h == 0 ? sh : split, hi = (h == 0 && cnt > 32) ? split : end;
-        stream_out_range<(kStageTris * REC + 3 + 255) / 256>(stage - 32 * REC * h, gal, lo, hi, lane, ablate);
+        stream_out_range<(kStageTris * REC + 3 + 255) / 256>(stage - 32 * REC * h, gal, lo, hi, lane, ablate, vm_issued);
     }
     VTMC_WAVE_SYNC();
 }
@@ -416,7 +621,7 @@ __device__ __forceinline__ void stream_records(float *stage, const float (&rec)[
 template <bool FAST>
 __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_vert, const unsigned short *s_own, size_t tri_base,
                                                    int tri_budget, size_t vert_base, int vert_budget, float *__restrict__ out_vertices,
-                                                   int *__restrict__ out_indices, int lane, int ablate, unsigned rowmask)
+                                                   int *__restrict__ out_indices, int lane, int ablate, unsigned rowmask, int &vm_issued)
 {
     const float *tile = L->tile;
     // pass 1: compaction of the active cells (as the soup path, row masks included; cases are re-derived where needed)
@@ -487,7 +692,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
                 }
             }
             const int cnt = n_w - s0 < 64 ? n_w - s0 : 64;
-            stream_records<kVertDwords, kStageTris * kVertDwords + 6>(L->stage, rec, cnt, out_vertices, (vert_base + (size_t)(window + s0)) * kVertDwords, lane, ablate);
+            stream_records<kVertDwords, kStageTris * kVertDwords + 6>(L->stage, rec, cnt, out_vertices, (vert_base + (size_t)(window + s0)) * kVertDwords, lane, ablate, vm_issued);
         }
         VTMC_WAVE_SYNC();
     }
@@ -514,7 +719,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
                 }
             }
             const int cnt = pending - s0 < 64 ? pending - s0 : 64;
-            stream_records<3, kStageTris * kVertDwords + 6>(L->stage, rec, cnt, reinterpret_cast<float *>(out_indices), (base + (size_t)s0) * 3, lane, ablate);
+            stream_records<3, kStageTris * kVertDwords + 6>(L->stage, rec, cnt, reinterpret_cast<float *>(out_indices), (base + (size_t)s0) * 3, lane, ablate, vm_issued);
         }
     };
     int pending = 0;

@@ -10,6 +10,92 @@
 namespace vtmc {
 
 // ----------------------------------------------------------------------------------------------
+// Loads hipcc does not count.  gfx950 keeps ONE counter (vmcnt) for vector loads, stores and returning
+// atomics, retired in issue order.  A wave that prefetches its next tile, emits a data-dependent number
+// of stores and then needs the tile gets `s_waitcnt vmcnt(0)` from the compiler -- it waits for every
+// store of the block it has just written (round 2: three such waits per block, 43 % of the wave cycles
+// parked).  The tile loads and the ticket atomic are therefore issued from inline asm, invisible to the
+// compiler's bookkeeping, and retired by wait_vm_at_most(n): n = a LOWER bound of the vector-memory
+// instructions issued after them (the body stores of the flush, counted in a scalar register), rounded
+// down to a step of the ladder below.  The destination registers travel through the statements as "+v"
+// operands, so no consumer is scheduled above the wait; tests/test_isa_audit.py checks in the compiled
+// ISA that nothing else touches them between issue and wait.
+// ----------------------------------------------------------------------------------------------
+// Every statement is UNCONDITIONAL for the compiler -- a wave-uniform skip is a branch inside the string, a lane that needs
+// nothing loads a harmless address -- so a destination register has one definition chain and no merge (phi) a copy could be
+// inserted for while the data is still in flight.
+// one tile-row load: skipped as a whole when bit `BIT` of the wave-uniform `live` is clear
+template <int BIT, bool FIRST>
+__device__ __forceinline__ void gload_async(float &dst, unsigned voff, const char *sbase, unsigned live)
+{
+    // FIRST: the base may come straight out of a v_readlane (an SGPR reloaded from its spill lane): a VALU-written SGPR needs five
+    // wait states before a VMEM instruction reads it, and hipcc pads nothing inside the string.  The later bases of a tile are
+    // scalar adds on the first (tools/isa_audit.py checks that no VALU write of a base sits within five instructions of its load).
+    if (FIRST)
+        asm volatile("s_bitcmp0_b32 %3, %4\n\ts_cbranch_scc1 .Lskip_%=\n\ts_nop 4\n\tglobal_load_dword %0, %1, %2\n.Lskip_%=:"
+                     : "+v"(dst)
+                     : "v"(voff), "s"(sbase), "s"(live), "n"(BIT)
+                     : "scc", "memory");
+    else
+        asm volatile("s_bitcmp0_b32 %3, %4\n\ts_cbranch_scc1 .Lskip_%=\n\tglobal_load_dword %0, %1, %2\n.Lskip_%=:"
+                     : "+v"(dst)
+                     : "v"(voff), "s"(sbase), "s"(live), "n"(BIT)
+                     : "scc", "memory");
+}
+// lane 0 takes the next ticket of `counter` (nothing happens when counter is null: static distribution)
+__device__ __forceinline__ void ticket_async(unsigned &dst, unsigned *counter)
+{
+    unsigned long long keep;
+    asm volatile("s_cmp_eq_u64 %4, 0\n\ts_cbranch_scc1 .Lnone_%=\n\t"
+                 "s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\ts_nop 4\n\t"   // the counter's address may be fresh from a v_readlane
+                 "global_atomic_add %0, %2, %3, %4 sc0\n\t"
+                 "s_mov_b64 exec, %1\n.Lnone_%=:"
+                 : "+v"(dst), "=&s"(keep)
+                 : "v"(0u), "v"(1u), "s"(counter)
+                 : "scc", "memory");
+}
+// waits until at most min(n, 48) of the wave's vector-memory instructions are outstanding (n wave-uniform)
+#define VTMC_WAIT_LADDER                                                                                   \
+    "s_cmp_lt_u32 %[n], 8\n\ts_cbranch_scc1 .Llt8_%=\n\t"                                                  \
+    "s_cmp_lt_u32 %[n], 20\n\ts_cbranch_scc1 .Llt20_%=\n\t"                                                \
+    "s_cmp_lt_u32 %[n], 32\n\ts_cbranch_scc1 .Llt32_%=\n\t"                                                \
+    "s_cmp_lt_u32 %[n], 48\n\ts_cbranch_scc1 .Lw32_%=\n\t"                                                 \
+    "s_waitcnt vmcnt(48)\n\ts_branch .Ldone_%=\n"                                                          \
+    ".Lw32_%=:\n\ts_waitcnt vmcnt(32)\n\ts_branch .Ldone_%=\n"                                             \
+    ".Llt32_%=:\n\ts_cmp_lt_u32 %[n], 24\n\ts_cbranch_scc1 .Lw20_%=\n\t"                                   \
+    "s_waitcnt vmcnt(24)\n\ts_branch .Ldone_%=\n"                                                          \
+    ".Lw20_%=:\n\ts_waitcnt vmcnt(20)\n\ts_branch .Ldone_%=\n"                                             \
+    ".Llt20_%=:\n\ts_cmp_lt_u32 %[n], 12\n\ts_cbranch_scc1 .Llt12_%=\n\t"                                  \
+    "s_cmp_lt_u32 %[n], 16\n\ts_cbranch_scc1 .Lw12_%=\n\t"                                                 \
+    "s_waitcnt vmcnt(16)\n\ts_branch .Ldone_%=\n"                                                          \
+    ".Lw12_%=:\n\ts_waitcnt vmcnt(12)\n\ts_branch .Ldone_%=\n"                                             \
+    ".Llt12_%=:\n\ts_cmp_lt_u32 %[n], 10\n\ts_cbranch_scc1 .Lw8_%=\n\t"                                    \
+    "s_waitcnt vmcnt(10)\n\ts_branch .Ldone_%=\n"                                                          \
+    ".Lw8_%=:\n\ts_waitcnt vmcnt(8)\n\ts_branch .Ldone_%=\n"                                               \
+    ".Llt8_%=:\n\ts_cmp_lt_u32 %[n], 4\n\ts_cbranch_scc1 .Llt4_%=\n\t"                                     \
+    "s_cmp_lt_u32 %[n], 6\n\ts_cbranch_scc1 .Lw4_%=\n\t"                                                   \
+    "s_waitcnt vmcnt(6)\n\ts_branch .Ldone_%=\n"                                                           \
+    ".Lw4_%=:\n\ts_waitcnt vmcnt(4)\n\ts_branch .Ldone_%=\n"                                               \
+    ".Llt4_%=:\n\ts_cmp_lt_u32 %[n], 2\n\ts_cbranch_scc1 .Llt2_%=\n\t"                                     \
+    "s_cmp_lt_u32 %[n], 3\n\ts_cbranch_scc1 .Lw2_%=\n\t"                                                   \
+    "s_waitcnt vmcnt(3)\n\ts_branch .Ldone_%=\n"                                                           \
+    ".Lw2_%=:\n\ts_waitcnt vmcnt(2)\n\ts_branch .Ldone_%=\n"                                               \
+    ".Llt2_%=:\n\ts_cmp_lt_u32 %[n], 1\n\ts_cbranch_scc1 .Lw0_%=\n\t"                                      \
+    "s_waitcnt vmcnt(1)\n\ts_branch .Ldone_%=\n"                                                           \
+    ".Lw0_%=:\n\ts_waitcnt vmcnt(0)\n"                                                                     \
+    ".Ldone_%=:"
+// the tile registers and the ticket pass through the wait: whatever reads them comes after it
+__device__ __forceinline__ void wait_vm_at_most(int n, float (&t)[20], unsigned &tick)
+{
+    asm volatile(VTMC_WAIT_LADDER
+                 : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]), "+v"(t[9]),
+                   "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15]), "+v"(t[16]), "+v"(t[17]), "+v"(t[18]),
+                   "+v"(t[19]), "+v"(tick)
+                 : [n] "s"(n)
+                 : "scc", "memory");
+}
+
+// ----------------------------------------------------------------------------------------------
 // emit_kernel: SampleNormal + MarchingCube fused, one wave per non-empty block, persistent waves.
 //   * each XCD (blockIdx % 8, round-robin dispatch -- a speed heuristic only) sweeps contiguous
 //     parts of the active list through per-part ticket counters, so blocks that share halo rows /
@@ -20,8 +106,12 @@ namespace vtmc {
 // ----------------------------------------------------------------------------------------------
 //   INDEXED: welded vertices + block-local indices (emit_block_indexed) instead of 76-byte records;
 //   `out` then is the vertex buffer, voffsets / vcapacity / out_indices its extra operands.
-template <bool FAST, bool INDEXED>
-__global__ __launch_bounds__(256, 4) void emit_kernel(BlockSpace sp, DeviceTables tb,
+//   ASYNC: the next tile and the next ticket travel outside the compiler's vmcnt bookkeeping (gload_async above) and a block's
+//   stores are never waited for; !ASYNC is round 2's loop (kept for same-box A/Bs: tuning key "emit_async").
+//   ONCE (soup only): every welded vertex of a block is evaluated one time into LDS and the records are expanded from there
+//   (emit_block_once, emit_device.h); 53 KB of LDS per workgroup: three workgroups per CU.
+template <bool FAST, bool INDEXED, bool ASYNC, bool ONCE = false>
+__global__ __launch_bounds__(256, ONCE ? 3 : 4) void emit_kernel(BlockSpace sp, DeviceTables tb,
                                                     const uint32_t *__restrict__ offsets,
                                                     const int32_t *__restrict__ active_list,
                                                     const uint32_t *__restrict__ totals, uint32_t capacity,
@@ -30,14 +120,18 @@ __global__ __launch_bounds__(256, 4) void emit_kernel(BlockSpace sp, DeviceTable
                                                     uint32_t vcapacity, int *__restrict__ out_indices,
                                                     const uint32_t *__restrict__ rowmasks, uint32_t *__restrict__ volume_counts, int n_volumes)
 {
-    using Lds = typename std::conditional<INDEXED, EmitLdsIdx, EmitLds2>::type;
+    static_assert(!(ONCE && INDEXED), "ONCE is a form of the soup");
+    using Lds = typename std::conditional<INDEXED, EmitLdsIdx, typename std::conditional<ONCE, EmitLdsOnce, EmitLds2>::type>::type;
     __shared__ Lds s_lds[kWavesPerWg];
     __shared__ u64 s_vert[256];
+    struct NoTables { unsigned char unused; };
+    __shared__ typename std::conditional<ONCE, OnceTables, NoTables>::type s_once[1];
     __shared__ unsigned short s_own[INDEXED ? 96 : 1];   // (cube edge, which coordinates are 7) -> owner cell offset | owner-side edge id
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     s_vert[threadIdx.x] = tb.vert_packed[threadIdx.x];
     if (INDEXED && threadIdx.x < 96) s_own[threadIdx.x] = owner_entry(threadIdx.x >> 3, threadIdx.x & 7u);
+    if constexpr (ONCE) once_tables_init(&s_once[0], threadIdx.x);
 #ifdef VTMC_DEBUG_POISON_LDS  // diagnostic build: NaN-fill LDS so any read of a never-written word shows up in the output
     for (unsigned i = threadIdx.x; i < sizeof(s_lds) / 4; i += 256) reinterpret_cast<unsigned *>(s_lds)[i] = 0x7FC00000u;
 #endif
@@ -59,6 +153,10 @@ __global__ __launch_bounds__(256, 4) void emit_kernel(BlockSpace sp, DeviceTable
     if (INDEXED && vtotals[0] > vcapacity) return;
 
     Lds *L = &s_lds[wave];
+    auto tile_of = [](Lds *l) -> float * {
+        if constexpr (ONCE) return l->c.tile;
+        else return l->tile;
+    };
 
     // Tile fetch: an instruction covers 5 rows of 10 samples (lane = sample along the stride-1 axis +
     // 10 * row-in-group; lanes 50-63 idle), 20 instructions cover the 100 rows.  A lane's address is one
@@ -139,8 +237,88 @@ __global__ __launch_bounds__(256, 4) void emit_kernel(BlockSpace sp, DeviceTable
     auto collect = [&]() { return ai_begin + (int)__builtin_amdgcn_readfirstlane(tick_raw); };
 
     float pre[20] = {};  // rows a block does not need keep whatever an earlier block left: never used
+    if constexpr (ASYNC) {
+        // the same two row groups, issued from inline asm: the compiler neither counts nor waits for them.  A lane that needs no
+        // row reads the tile's first sample instead (one address for all of them: a broadcast hit), a slab nobody needs is skipped.
+        auto load_rows_async = [&](const char *src, unsigned mask, float (&dst)[20]) {
+            const unsigned ym = mask & 0xFFu, zm = mask >> 8;
+            const unsigned ny = ym | (ym << 1) | (ym << 2), nz = zm | (zm << 1) | (zm << 2);
+            const bool zl = sp.zfast ? ((nz >> lq) & 1u) != 0u : true;
+            const bool need0 = lane_ok && zl && ((ny >> rqc) & 1u), need1 = lane_ok && zl && ((ny >> (5 + rqc)) & 1u);
+            const unsigned o0 = need0 ? off0 : 0u, o1 = need1 ? off1 : 0u;
+            const unsigned live = sp.zfast ? 0x3FFu : nz;   // x-fastest: a z slab nobody needs is skipped (wave-uniform)
+            const char *p = src;
+#define VTMC_ROW(C)                                  \
+    gload_async<C, true>(dst[2 * C], o0, p, live);         \
+    gload_async<C, false>(dst[2 * C + 1], o1, p, live);     \
+    p += slab_bytes;
+            VTMC_ROW(0) VTMC_ROW(1) VTMC_ROW(2) VTMC_ROW(3) VTMC_ROW(4) VTMC_ROW(5) VTMC_ROW(6) VTMC_ROW(7) VTMC_ROW(8) VTMC_ROW(9)
+#undef VTMC_ROW
+        };
+        // Tickets run two blocks ahead of the tile loads and three ahead of the work: at the top of step k the wave knows blocks k and
+        // k + 1 (id, row mask, offsets: scalar loads issued a step earlier), holds tile k in flight in `pre` and ticket k + 2 in `tick`.
+        struct Blk {
+            int b;
+            unsigned mask;
+            uint32_t tri_base, tri_end, vert_base, vert_end;
+        };
+        auto describe = [&](int entry) {   // scalar loads only (lgkmcnt): nothing here touches vmcnt
+            Blk d{-1, 0xFFFFu, 0u, 0u, 0u, 0u};
+            if (entry < ai_end) {
+                d.b = active_list[(ablate & 2) ? ai_begin + (entry & 3) : entry];
+                if (rowmasks) d.mask = rowmasks[d.b] >> 16;
+                d.tri_base = offsets[d.b];
+                d.tri_end = offsets[d.b + 1];
+                if constexpr (INDEXED) {
+                    d.vert_base = voffsets[d.b];
+                    d.vert_end = voffsets[d.b + 1];
+                }
+            }
+            return d;
+        };
+        unsigned tick = 0;        // written by the asm atomic only (lane 0)
+        int tick_static = 0;      // static distribution: the entry, kept in a scalar register
+        unsigned *const counter = queue ? queue + part * 64 : nullptr;
+        auto request_async = [&]() {
+            ticket_async(tick, counter);
+            if (!queue) tick_static = entry(k_static++);
+        };
+        auto collect_async = [&]() { return queue ? ai_begin + (int)__builtin_amdgcn_readfirstlane(tick) : tick_static; };
+        int vm_issued = 0;
+        request_async();
+        wait_vm_at_most(0, pre, tick);
+        Blk cur = describe(collect_async());
+        request_async();
+        wait_vm_at_most(0, pre, tick);
+        Blk nxt = describe(collect_async());
+        if (cur.b >= 0) load_rows_async(reinterpret_cast<const char *>(sp.base + block_origin(sp, cur.b)), cur.mask, pre);
+        request_async();
+        while (cur.b >= 0) {
+            wait_vm_at_most(vm_issued, pre, tick);   // tile `cur` and the ticket of the block after `nxt` have landed; younger stores stay in flight
+            vm_issued = 0;
+            VTMC_WAVE_SYNC();
+            store_tile(tile_of(L), pre);
+            const int far_entry = collect_async();
+            if (nxt.b >= 0) load_rows_async(reinterpret_cast<const char *>(sp.base + block_origin(sp, nxt.b)), nxt.mask, pre);
+            request_async();
+            const Blk far = describe(far_entry);   // two dependent scalar loads: behind the tile loads, so only the wave's own LDS work waits for them
+            VTMC_WAVE_SYNC();
+            const int budget = (int)(cur.tri_end - cur.tri_base);
+            if constexpr (INDEXED)
+                emit_block_indexed<FAST>(L, s_vert, s_own, (size_t)cur.tri_base, budget, (size_t)cur.vert_base, (int)(cur.vert_end - cur.vert_base), out,
+                                         out_indices, lane, ablate, cur.mask, vm_issued);
+            else if constexpr (ONCE)
+                emit_block_once<FAST>(L, s_vert, &s_once[0], (size_t)cur.tri_base, budget, cur.b, out, lane, ablate, cur.mask, vm_issued);
+            else
+                emit_block_from_tile<FAST>(L, s_vert, (size_t)cur.tri_base, budget, cur.b, out, lane, ablate, cur.mask, vm_issued);
+            cur = nxt;
+            nxt = far;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last ticket (nobody reads it) has landed before the wave ends
+    } else {
     int b_next = 0;
     unsigned mask_next = 0xFFFFu;
+    int vm_unused = 0;
     request();
     int ai = collect();
     request();
@@ -156,7 +334,7 @@ __global__ __launch_bounds__(256, 4) void emit_kernel(BlockSpace sp, DeviceTable
         const size_t tri_base = offsets[b];
         const int budget = (int)(offsets[b + 1] - offsets[b]);  // the scan's count for this block
         VTMC_WAVE_SYNC();
-        store_tile(L->tile, pre);
+        store_tile(tile_of(L), pre);
         if (ai_next < ai_end) {  // prefetch the next block's tile; it lands while this one is processed
             b_next = active_list[(ablate & 2) ? ai_begin + (k & 3) : ai_next];
             if (rowmasks) mask_next = rowmasks[b_next] >> 16;
@@ -167,11 +345,14 @@ __global__ __launch_bounds__(256, 4) void emit_kernel(BlockSpace sp, DeviceTable
 
         if constexpr (INDEXED)
             emit_block_indexed<FAST>(L, s_vert, s_own, tri_base, budget, (size_t)voffsets[b], (int)(voffsets[b + 1] - voffsets[b]), out,
-                                     out_indices, lane, ablate, mask);
+                                     out_indices, lane, ablate, mask, vm_unused);
+        else if constexpr (ONCE)
+            emit_block_once<FAST>(L, s_vert, &s_once[0], tri_base, budget, b, out, lane, ablate, mask, vm_unused);
         else
-            emit_block_from_tile<FAST>(L, s_vert, tri_base, budget, b, out, lane, ablate, mask);
+            emit_block_from_tile<FAST>(L, s_vert, tri_base, budget, b, out, lane, ablate, mask, vm_unused);
         ai = ai_next;
         ai_next = collect();
+    }
     }
 }
 
@@ -180,17 +361,24 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
                        void *triangles, int n_cus, const Tuning &tune, unsigned *queue, uint32_t *volume_counts, int n_volumes,
                        hipStream_t stream)
 {
-    int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : 4;  // 4 x 40 KB of LDS, 128 VGPRs
+    const bool once = tune.emit_once && tune.emit_fast_math && tune.emit_async;   // the exact mode stays bit-compatible with the oracle: per-corner evaluation
+    int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : (once ? 3 : 4);  // 4 x 40 KB of LDS, 128 VGPRs; vertex-once: 3 x 53 KB
     int wgs = n_cus * per_cu;
     wgs = (wgs + 7) & ~7;  // the XCD sweep needs a multiple of 8
     if (wgs > 8 + tune.emit_spare_wgs) wgs -= tune.emit_spare_wgs & ~7;
     dim3 g(wgs), blk(256);
     float *o = (float *)triangles;
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
-    if (tune.emit_fast_math)
-        hipLaunchKernelGGL((emit_kernel<true, false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes);
-    else
-        hipLaunchKernelGGL((emit_kernel<false, false>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes);
+#define VTMC_LAUNCH_SOUP(F, A, ...) hipLaunchKernelGGL((emit_kernel<F, false, A, ##__VA_ARGS__>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes)
+    if (once) VTMC_LAUNCH_SOUP(true, true, true);
+    else if (tune.emit_fast_math) {
+        if (tune.emit_async) VTMC_LAUNCH_SOUP(true, true);
+        else VTMC_LAUNCH_SOUP(true, false);
+    } else {
+        if (tune.emit_async) VTMC_LAUNCH_SOUP(false, true);
+        else VTMC_LAUNCH_SOUP(false, false);
+    }
+#undef VTMC_LAUNCH_SOUP
     return hipGetLastError();
 }
 
@@ -206,10 +394,15 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
     if (wgs > 8 + tune.emit_spare_wgs) wgs -= tune.emit_spare_wgs & ~7;
     dim3 g(wgs), blk(256);
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
-    if (tune.emit_fast_math)
-        hipLaunchKernelGGL((emit_kernel<true, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes);
-    else
-        hipLaunchKernelGGL((emit_kernel<false, true>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes);
+#define VTMC_LAUNCH_IDX(F, A) hipLaunchKernelGGL((emit_kernel<F, true, A>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes)
+    if (tune.emit_fast_math) {
+        if (tune.emit_async) VTMC_LAUNCH_IDX(true, true);
+        else VTMC_LAUNCH_IDX(true, false);
+    } else {
+        if (tune.emit_async) VTMC_LAUNCH_IDX(false, true);
+        else VTMC_LAUNCH_IDX(false, false);
+    }
+#undef VTMC_LAUNCH_IDX
     return hipGetLastError();
 }
 

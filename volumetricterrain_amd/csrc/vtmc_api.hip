@@ -707,6 +707,8 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     if (k == "emit_fast_math") ctx->tune.emit_fast_math = value;
     else if (k == "emit_sub_log2") ctx->tune.emit_sub_log2 = value < 0 ? 0 : (value > 4 ? 4 : value);
     else if (k == "emit_dynamic") ctx->tune.emit_dynamic = value;
+    else if (k == "emit_async") ctx->tune.emit_async = value;
+    else if (k == "emit_once") ctx->tune.emit_once = value;
     else if (k == "emit_ablate") ctx->tune.emit_ablate = value;
     else if (k == "classify_ablate") ctx->tune.classify_ablate = value;
     else if (k == "emit_row_masks") ctx->tune.emit_row_masks = value;
