@@ -69,10 +69,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chunks", type=int, default=32, help="chunks the CPU oracle is timed on")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0: physical cores in this process's CPU share, at most 16 per GPU)")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
-                    help="grid1024: steps in flight.  2 (default): two contexts take turns, step k + 1 is queued before the host takes step "
-                         "k's result -- the device never waits for the host; 1: every step ends with its host wait (the latency of an "
-                         "isolated step, also reported as step_latency_ms)")
+    ap.add_argument("--pipeline", type=int, default=None, choices=[1, 2],
+                    help="grid1024: steps in flight.  2 (the default at N = 1): two contexts take turns, step k + 1 is queued before the host "
+                         "takes step k's result -- the device never waits for the host; 1 (the default at N > 1: ONE context, ONE communicator, "
+                         "the collective behind the emit kernel on the extract's own stream -- the configuration with the fewest parts that "
+                         "have never run with a world > 1): every step ends with its host wait (also reported as step_latency_ms)")
+    ap.add_argument("--gather-beside", action="store_true",
+                    help="N > 1, opt-in: the all-gather on the context's second stream beside the emit kernel (tuning key gather_beside)")
     ap.add_argument("--no-dense", action="store_true", help="A/B: force the per-block classify kernel")
     ap.add_argument("--no-indexed", action="store_true", help="skip the extra indexed-output steps at N = 1")
     args = ap.parse_args()
@@ -280,9 +283,12 @@ def run_grid(args, torch, dist):
     n_chunks_total = (world_dims[0] // c) * (world_dims[1] // c) * (world_dims[2] // c)
     per_rank = (n_chunks_total + world - 1) // world   # slots per rank in the gathered array (zero-padded)
     bpv = (c // 8) ** 3
-    depth = args.pipeline
+    depth = args.pipeline if args.pipeline else (2 if world == 1 else 1)
     exs = [vt.Extractor(local) for _ in range(depth)]   # depth 2: the contexts take turns, each with its own result buffers (and communicator)
     ex = exs[0]
+    if args.gather_beside:
+        for e in exs:
+            e.set_tuning(gather_beside=1)
     # one explicit (non-default) HIP stream for everything: the library's kernels, the all-gather and the
     # copy of the gathered counts are ordered by it
     stream = torch.cuda.Stream()

@@ -164,13 +164,17 @@ int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4]);
 /* Selects a kernel variant / launch shape, mainly for A/B measurements in one process.  Keys that
  * keep results within the parity bar: "emit_fast_math" (1: v_rcp / v_rsq / fma, default; 0: correctly
  * rounded, bit-compatible with the CPU oracle), "emit_wgs_per_cu", "emit_dynamic",
- * "emit_sub_log2", "emit_group_log2", "gather_beside".  "emit_ablate" / "classify_ablate" switch parts of a kernel
- * off for diagnosis and make the output INVALID.  Defaults are the shipped configuration.
+ * "emit_sub_log2", "emit_group_log2", "gather_beside" (default 0: the all-gather of a queued extract runs behind the emit kernel on
+ * the caller's stream; 1: beside it on the context's second stream), "emit_async" (default 1: tile prefetch and tickets outside the
+ * compiler's vmcnt bookkeeping; 0: round 2's loop), "emit_once" (default 1: with emit_fast_math, every welded vertex of a block is
+ * evaluated once and the 76-byte records are expanded from LDS; 0: per triangle corner).  "emit_ablate" / "classify_ablate" switch parts
+ * of a kernel off for diagnosis and make the output INVALID.  Defaults are the shipped configuration.
  * "fill_keeps_signs" (default 0) is a contract, not a variant: with 1, vtmc_density_fill_device[_async] also leaves
  * one sign bit per sample in context memory, and an extract by the SAME context of exactly that buffer (pointer,
  * dims, strides, volume count) classifies from those bits instead of the samples (1/32 of the bytes; results are
  * identical).  The caller vouches that nothing wrote to the buffer between the fill and the extract; any other
- * fill by the context, or setting the key again, drops the bits.  streaming.ChunkStream sets it. */
+ * fill by the context, setting the key again, or "invalidate_signs" (any value) drops the bits -- a caller whose allocator may hand the
+ * same address to a new buffer of the same shape calls that when it frees the old one.  streaming.ChunkStream sets it. */
 int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value);
 
 /* Synthetic density sampler (the reference has no noise field of its own):

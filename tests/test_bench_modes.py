@@ -52,6 +52,7 @@ def test_strong_scaling_two_ranks_on_one_device():
     assert j["config"]["chunks_per_gpu"] == 4 and "c -> rank c % 2" in j["config"]["workload"]
     assert abs(j["triangles_total"] - 2655156) < 2000 and 0 < j["triangles_rank0"] < j["triangles_total"]
     assert j["allgather_ms"]["avg"] >= 0 and j["cpu_baseline"] is None
+    assert j["pipeline_depth"] == 1   # N > 1 default: one context, one communicator, the collective behind the emit kernel
 
 
 def test_stream_config_line():
@@ -72,3 +73,7 @@ def test_exchange_path_through_a_world_of_one_communicator():
     j1 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--pipeline", "1"],
              {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j1["pipeline_depth"] == 1 and j1["triangles_total"] == j["triangles_total"]
+    # opt-in: the collective beside the emit kernel, two contexts / communicators taking turns
+    j2 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--pipeline", "2",
+              "--gather-beside"], {"VTMC_BENCH_FORCE_COMM": "1"})
+    assert j2["pipeline_depth"] == 2 and j2["triangles_total"] == j["triangles_total"]

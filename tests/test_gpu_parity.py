@@ -662,5 +662,30 @@ def test_chunk_file_written_and_reloaded_on_the_device(ex, oracle_mod, tmp_path,
             with pytest.raises(vt.VtmcError) as err:
                 e2.chunk_read(tmp_path / "bad")
             assert err.value.code == -1
+            # hostile headers: counts far beyond the file (must be refused before anything is allocated), cells beyond the
+            # format's limit, unknown flags, a truncated body -- VTMC_ERR_INVALID_ARG each time, the process stays alive
+            good = bytearray(open(path, "rb").read())
+            import struct
+
+            def patched(offset, fmt, *values):
+                b = bytearray(good)
+                struct.pack_into(fmt, b, offset, *values)
+                return bytes(b)
+
+            hostile = {
+                "huge_triangles": patched(44, "<I", 0xFFFFFFF0),                 # n_triangles
+                "huge_vertices": patched(48, "<I", 0xFFFFFFF0),                  # n_vertices
+                "huge_cells": patched(28, "<iii", 0x7FFFFFF8, 8, 8),             # cells: + 2 would overflow int32
+                "blocks_mismatch": patched(40, "<I", bpv + 1),
+                "unknown_flags": patched(12, "<I", 0x80000000 | struct.unpack_from("<I", good, 12)[0]),
+                "truncated": bytes(good[:len(good) - 16]),
+                "trailing_bytes": bytes(good) + b"\0" * 16,
+            }
+            for name, blob in hostile.items():
+                (tmp_path / name).write_bytes(blob)
+                with pytest.raises(vt.VtmcError) as err:
+                    e2.chunk_read(tmp_path / name)
+                assert err.value.code == -1, name
+            assert e2.chunk_read(path).n_triangles == view.n_triangles   # and the good file still loads
     finally:
         ex.set_output_mode(False)

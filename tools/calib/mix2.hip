@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -92,6 +93,61 @@ __global__ __launch_bounds__(256) void emit_shape_kernel(const float *__restrict
     }
 }
 
+
+// Write-only, in the emit kernel's own granularity: every wave writes whole chunks of `chunk_f4` float4 (a block's records: 608 for
+// the average block) with back-to-back 1-KiB store instructions.  MODE 0: chunk = it * n_waves + wave (what a static round-robin over
+// the active list does); MODE 1: the four waves of a workgroup write ONE chunk together (wave w the w-th KiB of every 4 KiB);
+// MODE 2: like 0 but a dependent ~`spin`-instruction delay between two store instructions of a wave (stores trickle out, as they do
+// between the staging rounds of a flush).
+template <int MODE>
+__global__ __launch_bounds__(256) void chunk_write_kernel(v4f *__restrict__ dst, long long n_chunks, int chunk_f4, int spin)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const v4f val = {1.f, 2.f, 3.f, (float)lane};
+    if (MODE == 1) {
+        for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+            v4f *o = dst + c * chunk_f4;
+            for (int i = w * 64 + lane; i < chunk_f4; i += 256) o[i] = val;
+        }
+    } else {
+        const long long wave = (long long)blockIdx.x * 4 + w, n_waves = (long long)gridDim.x * 4;
+        float a = (float)lane;
+        for (long long c = wave; c < n_chunks; c += n_waves) {
+            v4f *o = dst + c * chunk_f4;
+            for (int i = lane; i < chunk_f4; i += 64) {
+                if (MODE == 2) {
+                    for (int k = 0; k < spin; ++k) a = __builtin_fmaf(a, 1.0000001f, 0.5f);
+                    o[i] = (v4f){a, 2.f, 3.f, 4.f};
+                } else {
+                    o[i] = val;
+                }
+            }
+        }
+    }
+}
+
+template <int MODE>
+static void run_chunks(const char *name, int wgs_per_cu, int n_cus, v4f *dst, long long total_f4, int chunk_f4, int spin, int reps)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const long long n_chunks = total_f4 / chunk_f4;
+    std::vector<float> ms(reps);
+    for (int i = 0; i < reps + 1; ++i) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((chunk_write_kernel<MODE>), dim3(wgs_per_cu * n_cus), dim3(256), 0, 0, dst, n_chunks, chunk_f4, spin);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        if (i) CK(hipEventElapsedTime(&ms[i - 1], e0, e1));
+    }
+    std::sort(ms.begin(), ms.end());
+    const double bytes = (double)n_chunks * chunk_f4 * 16.0;
+    printf("{\"kernel\": \"%s\", \"mode\": %d, \"chunk_bytes\": %d, \"spin\": %d, \"wgs_per_cu\": %d, \"GB\": %.3f, \"ms_med\": %.4f, \"TBps_med\": %.3f, "
+           "\"TBps_best\": %.3f}\n", name, MODE, chunk_f4 * 16, spin, wgs_per_cu, bytes / 1e9, ms[reps / 2], bytes / ms[reps / 2] / 1e9, bytes / ms[0] / 1e9);
+    fflush(stdout);
+}
+
 template <int R, int W, int U, bool NT>
 static void run(const char *name, int wgs_per_cu, int n_cus, const v4f *src, v4f *dst, long long n_units, int reps)
 {
@@ -128,6 +184,17 @@ int main(int argc, char **argv)
     CK(hipMalloc(&buf, total_f4 * 16));
     CK(hipMemset(buf, 0, total_f4 * 16));
     const int reps = 7;
+
+    if (argc > 2 && !strcmp(argv[2], "chunks")) {
+        const long long f4 = (3ll << 30) / 16;   // 3 GiB written per launch (the emit kernel writes 3.23 GB)
+        for (int per_cu : {4, 3, 2}) {
+            for (int chunk : {152, 304, 608, 1216, 2432, 9728}) run_chunks<0>("chunk_write", per_cu, n_cus, buf, f4, chunk, 0, reps);
+            for (int chunk : {608, 2432}) run_chunks<1>("chunk_write_wg", per_cu, n_cus, buf, f4, chunk, 0, reps);
+            for (int spin : {100, 400, 1600}) run_chunks<2>("chunk_write_trickle", per_cu, n_cus, buf, f4, 608, spin, reps);
+        }
+        CK(hipFree(buf));
+        return 0;
+    }
 #define SWEEP(R, W, NAME)                                                                     \
     {                                                                                         \
         const long long n_units = total_f4 / (R + W);                                         \

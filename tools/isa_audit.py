@@ -73,9 +73,10 @@ def audit_kernel(name, lines):
             if any("s_waitcnt vmcnt" in b for b in block):
                 pending = {}
             for b in block:
-                m = re.match(r"\s*(global_load_dword|global_atomic_add)\s+v(\d+)\s*,", b)
+                m = re.match(r"\s*(global_load_dword(?:x2)?|global_atomic_add)\s+(v\d+|v\[\d+:\d+\])\s*,", b)
                 if m:
-                    pending[int(m.group(2))] = i
+                    for r in regs_of(m.group(2)):
+                        pending[r] = i
                     n_loads += 1
             continue
         if in_asm:

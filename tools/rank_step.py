@@ -2,9 +2,10 @@
 """Strong-scaling rehearsal on ONE GPU: times the step of rank r of a W-rank run of BASELINE configs[3]
 (its 512 / W chunks of the 1024^3 world: queued extract + the one host wait, no collective) next to the
 whole 512-chunk step, i.e. the speed-up the sharding leaves before the all-gather's ~tens of microseconds.
-    python tools/rank_step.py [--comm | --comm-behind] [W ...]
---comm: every step also queues the C ABI's all-gather (a world-of-one RCCL communicator: the library's second
-stream, its events and the copy of the gathered array are real, the wire is not) -- the fixed cost of the exchange."""
+    python tools/rank_step.py [--comm | --comm-beside] [W ...]
+--comm: every step also queues the C ABI's all-gather (a world-of-one RCCL communicator: its stream ordering, events and
+the copy of the gathered array are real, the wire is not) -- the fixed cost of the exchange, behind the emit kernel on the
+extract's stream (the library's default); --comm-beside: on the context's second stream beside the emit kernel (opt-in)."""
 import os
 import sys
 import time
@@ -24,8 +25,8 @@ args = [a for a in sys.argv[1:] if not a.startswith("--comm")]
 with_comm = any(a.startswith("--comm") for a in sys.argv[1:])
 if with_comm:
     ex.comm_init_rank(ex.comm_unique_id(), 0, 1)
-    if "--comm-behind" in sys.argv[1:]:
-        ex.set_tuning(gather_beside=0)   # round 2a's order: the collective behind the emit kernel on the same stream
+    if "--comm-beside" in sys.argv[1:]:
+        ex.set_tuning(gather_beside=1)   # opt-in: the collective on the second stream, beside the emit kernel
 for W in [1] + [int(a) for a in args or ["2", "4", "8"]]:
     worst = 0.0
     for r in range(W):

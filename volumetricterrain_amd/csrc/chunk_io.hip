@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <new>
+#include <sys/stat.h>
 
 using namespace vtmc;
 
@@ -159,7 +161,12 @@ int32_t vtmc_chunk_write(vtmc_ctx *ctx, const char *path, int32_t volume, const 
                            (uint32_t)b0, (uint32_t *)(img + l.triangles));
     }
     VTMC_HIP(ctx, hipGetLastError());
-    std::vector<char> host(l.total);
+    std::vector<char> host;
+    try {   // nothing is thrown through the C boundary
+        host.resize(l.total);
+    } catch (const std::exception &) {
+        return fail(ctx, VTMC_ERR_DEVICE, "out of host memory for a chunk image of %zu bytes", l.total);
+    }
     VTMC_HIP(ctx, hipMemcpyAsync(host.data(), img, l.total, hipMemcpyDeviceToHost, st));
     VTMC_HIP(ctx, hipStreamSynchronize(st));
     FILE *f = fopen(path, "wb");
@@ -179,18 +186,33 @@ int32_t vtmc_chunk_read(vtmc_ctx *ctx, const char *path, vtmc_chunk_view *out)
     if (!f) return fail(ctx, VTMC_ERR_INVALID_ARG, "cannot open %s: %s", path, strerror(errno));
     std::vector<char> host;
     ChunkHeader h{};
+    // The header is untrusted input: every count is checked against the limits of the format and the image it implies against the
+    // size of the file BEFORE anything is allocated -- a corrupt or truncated header can neither request hundreds of gigabytes nor
+    // overflow the cells + 2 arithmetic, and no allocation failure crosses the C boundary.
     bool ok = fread(&h, 1, sizeof h, f) == sizeof h && memcmp(h.magic, "VTCHUNK1", 8) == 0 && h.version == 1;
-    ok = ok && h.cells[0] > 0 && h.cells[1] > 0 && h.cells[2] > 0 && h.cells[0] % 8 == 0 && h.cells[1] % 8 == 0 && h.cells[2] % 8 == 0 &&
-         (long long)h.n_blocks == (long long)(h.cells[0] / 8) * (h.cells[1] / 8) * (h.cells[2] / 8);
-    ChunkLayout l;
+    const uint32_t known_flags = kFlagSamples | kFlagSoup | kFlagIndexed;
+    ok = ok && (h.flags & ~known_flags) == 0u && ((h.flags & kFlagSoup) != 0u) != ((h.flags & kFlagIndexed) != 0u);
+    for (int k = 0; ok && k < 3; ++k) ok = h.cells[k] > 0 && h.cells[k] <= 1024 && h.cells[k] % 8 == 0;   // VoxelTerrain.cs:44: at most 1025 samples per axis
+    ok = ok && (long long)h.n_blocks == (long long)(h.cells[0] / 8) * (h.cells[1] / 8) * (h.cells[2] / 8);
+    ok = ok && (unsigned long long)h.n_triangles <= 2560ull * h.n_blocks && (unsigned long long)h.n_vertices <= 1944ull * h.n_blocks;   // per 8^3 block: 512 cells x 5, 3 x 648 lattice edges
+    ChunkLayout l{};
     if (ok) {
         l = layout_of(h);
-        host.resize(l.total);
+        struct stat sb;
+        ok = fstat(fileno(f), &sb) == 0 && (unsigned long long)sb.st_size == (unsigned long long)l.total;
+    }
+    if (ok) {
+        try {
+            host.resize(l.total);
+        } catch (const std::exception &) {
+            fclose(f);
+            return fail(ctx, VTMC_ERR_DEVICE, "out of host memory for a chunk image of %zu bytes", l.total);
+        }
         memcpy(host.data(), &h, sizeof h);
         ok = fread(host.data() + sizeof h, 1, l.total - sizeof h, f) == l.total - sizeof h;
     }
     fclose(f);
-    if (!ok) return fail(ctx, VTMC_ERR_INVALID_ARG, "%s is not a complete version-1 chunk file", path);
+    if (!ok) return fail(ctx, VTMC_ERR_INVALID_ARG, "%s is not a complete version-1 chunk file (bad magic, counts beyond the format's limits, or a size that does not match its header)", path);
     VTMC_HIP(ctx, hipSetDevice(ctx->device));
     VTMC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // nothing queued may still use the previous image
     if (int rc = ensure(ctx, ctx->chunk_image, l.total)) return rc;

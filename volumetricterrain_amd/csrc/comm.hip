@@ -11,7 +11,21 @@
 #include "vtmc_ctx.h"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+
+// The five entry points and four types of RCCL this file uses, declared here so that the library builds on a host without the RCCL
+// headers (a single-GPU host never loads librccl at all).  Values as in rccl.h / nccl.h (stable ABI): ncclSuccess = 0, ncclUint32 = 3,
+// a unique id of 128 bytes.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+    char internal[128];
+} ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+}
+static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclDataType_t ncclUint32 = 3;
+static constexpr int NCCL_UNIQUE_ID_BYTES = 128;
 
 #include <cstring>
 #include <mutex>
@@ -73,6 +87,10 @@ namespace vtmc {
 void comm_release(vtmc_ctx *ctx)
 {
     if (ctx && ctx->comm) {
+        // no collective of this communicator may still be queued when it is destroyed
+        if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+        if (ctx->pending.active && ctx->pending.stream) (void)hipStreamSynchronize(ctx->pending.stream);   // a queued extract's collective
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         const RcclApi &a = rccl();
         if (a.handle) (void)a.CommDestroy((ncclComm_t)ctx->comm);
         ctx->comm = nullptr;
@@ -144,6 +162,9 @@ int32_t vtmc_allgather_volume_counts(vtmc_ctx *ctx, uint32_t *d_all_counts, int3
     // kernel, which was launched a workgroup per XCD short for it; `stream` then only waits for its end.
     const bool beside = ctx->pending.active && ctx->pending.launched && ctx->pending.counts_early && ctx->pending.scan_event && ctx->tune.gather_beside;
     hipStream_t gs = st;
+    // not beside: the counts are read on `st`.  When that is not the stream the queued extract runs on, order the read behind the
+    // extract's emit launch (whose first workgroup may be the one that writes the per-volume counts)
+    if (!beside && ctx->pending.active && ctx->pending.launched && st != ctx->pending.stream) VTMC_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[3], 0));
     if (beside) {
         if (!ctx->comm_stream) VTMC_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
         if (!ctx->ev_gather) VTMC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_gather, hipEventDisableTiming));

@@ -676,8 +676,10 @@ int32_t vtmc_copy_volume_counts_device(vtmc_ctx *ctx, uint32_t *d_dst, int32_t c
     if (n_vol == 0 || n_blk == 0) return VTMC_OK;
     if (!d_dst) return fail(ctx, VTMC_ERR_INVALID_ARG, "d_dst is null");
     VTMC_HIP(ctx, hipSetDevice(ctx->device));
-    VTMC_HIP(ctx, hipMemcpyAsync(d_dst, ctx->volcounts.p, sizeof(uint32_t) * 2 * (size_t)n_vol, hipMemcpyDeviceToDevice,
-                                 stream ? (hipStream_t)stream : ctx->stream));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    // a queued extract on another stream: the copy is ordered behind its emit launch (whose first workgroup may write the counts)
+    if (ctx->pending.active && ctx->pending.launched && st != ctx->pending.stream) VTMC_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[3], 0));
+    VTMC_HIP(ctx, hipMemcpyAsync(d_dst, ctx->volcounts.p, sizeof(uint32_t) * 2 * (size_t)n_vol, hipMemcpyDeviceToDevice, st));
     return VTMC_OK;
 }
 
@@ -714,6 +716,7 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     else if (k == "emit_row_masks") ctx->tune.emit_row_masks = value;
     else if (k == "density_ablate") ctx->tune.density_ablate = value;
     else if (k == "density_wgs_per_cu") ctx->tune.density_wgs_per_cu = value;
+    else if (k == "invalidate_signs") ctx->sign_of.valid = false;   // the caller wrote to (or re-used the address of) a buffer the last fill left sign bits for
     else if (k == "fill_keeps_signs") {
         ctx->tune.fill_keeps_signs = value;
         ctx->sign_of.valid = false;

@@ -72,7 +72,7 @@ struct Tuning {
                                 // context then classifies from them (1/32 of the bytes) -- the streaming driver's setting
     int density_wgs_per_cu = 0;   // residency cap of the column sampler (0: four workgroups per CU); 3 leaves room for a concurrent extract
     int stage_events = 1;     // 1: events between the three kernels (vtmc_last_stage_ms per stage); 0: only around the whole step
-    int gather_beside = 1;    // 1: the all-gather of a queued extract runs on a second stream beside the emit kernel; 0: behind it
+    int gather_beside = 0;    // 1: the all-gather of a queued extract runs on a second stream beside the emit kernel (opt-in: never run with a world > 1); 0: behind it, on the caller's stream
     int emit_async = 1;       // 1: tile prefetch and tickets outside the compiler's vmcnt bookkeeping, a block's stores are never waited for (emit_kernels.hip); 0: round 2's loop
     int emit_once = 1;        // 1 (soup, fast math): every welded vertex of a block is evaluated once into LDS, records expanded from there; 0: per triangle corner
     int emit_spare_wgs = 0;   // workgroups the emit launch leaves free (one per XCD: room for the collective's kernel beside it)

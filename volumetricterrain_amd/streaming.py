@@ -61,8 +61,10 @@ class ChunkStream:
                                            self._buf[slot].data_ptr(), self._stream.cuda_stream, wait=False)
 
     def batches(self):
-        """Yields (k, origins, T, extractor): the extractor still holds batch k's results (triangles,
-        block offsets, per-chunk counts) until the generator is advanced twice more.
+        """Yields (k, origins, T, extractor): the extractor holds batch k's results (triangles, block offsets,
+        per-chunk counts) ONLY UNTIL THE GENERATOR IS NEXT ADVANCED -- batch k + 2 is extracted by the same context,
+        and the very next advance queues it over the same result buffers.  A consumer copies what it keeps before it
+        asks for the next batch (run() does); device pointers from device_results() must not be held across an advance.
         Stream order: S0 S1 E0 E1 S2 E2 S3 E3 ... (S = sample, E = extract); the host takes E(k - 1) while E(k) runs."""
         nb = self.n_batches()
         if nb == 0:
