@@ -198,6 +198,11 @@ def pmc_traffic(dom, matches):
         return None, None
     try:
         j = json.load(open(f))
+        from volumetricterrain_amd import build as vt_build
+        now = vt_build.kernel_source_hash()
+        if j.get("kernel_source_sha256") != now:   # the kernels changed since the PMC passes were taken: no stale constant
+            return None, "none: profiles/pmc_traffic.json was measured on other kernel sources (sha256 %s..., now %s...)" % (
+                str(j.get("kernel_source_sha256"))[:12], now[:12])
         return j.get(dom + "_hbm_bytes"), "committed constant: " + j.get("source", "profiles/pmc_traffic.json")
     except Exception:
         return None, None
@@ -468,7 +473,8 @@ def run_grid(args, torch, dist):
                            "output_bytes_vs_soup": round((24.0 * V + 12.0 * Ti) / (76.0 * Ti), 4),
                            "kernels_ms": {k: round(v, 4) for k, v in acc.items()},
                            "path_roofline": {"bytes": ibytes, "achieved_GBps": round(ibytes / (acc["total"] * 1e-3) / 1e9, 1),
-                                             "frac_of_peak": round(ibytes / (acc["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                                             "frac_of_peak": round(ibytes / (acc["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                             "read_only_frac_of_peak": round(4.0 * samples / (acc["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                            "speedup_over_soup_step": round(ms_per_step / ms_i, 3)}
             finally:
                 ex.set_output_mode(False)
@@ -509,7 +515,7 @@ def run_grid(args, torch, dist):
             "kernels": per_kernel,
             "path_roofline": path,
             "allgather_ms": None if not gather_ms else {"avg": round(statistics.mean(gather_ms), 4), "max": round(max(gather_ms), 4),
-                                                     "note": "rank 0, HIP events on the extract's stream from the end of the emit kernel to the end of the collective: what the collective adds to the step (it runs beside the emit kernel when the chunks are whole scan tiles); sampled on every eighth step"},
+                                                     "note": "rank 0, HIP events on the extract's stream from the end of the emit launch to the end of the collective: what the collective adds to the step (behind the emit kernel on that stream by default; beside it with --gather-beside); sampled on every eighth step"},
             "host_ms_per_step_beyond_kernels": round(ms_per_step - avg["total"], 4),
             "pipeline_depth": depth,
             "step_latency_ms": round(step_latency_ms, 4),

@@ -335,10 +335,10 @@ def test_sharded_host_entry(ex, oracle_mod):
 
 
 def test_density_sampler_matches_cpu_twin(ex, oracle_mod):
-    """The wave64 column sampler against the per-sample CPU twin (oracle/density_ref.c): x-fastest volumes
-    (walk along z, lane plane = one contiguous slab), the C# z-fastest layout and a padded x-fastest
-    volume (walk along y), several volumes with non-zero origins, 1 / 3 / 8 octaves, and the per-sample
-    kernel that serves more than 8 octaves."""
+    """The wave64 column sampler against the per-sample CPU twin (oracle/density_ref.c): x-fastest volumes, the C# z-fastest
+    layout and a padded x-fastest volume, several volumes with non-zero origins, 1 / 3 / 8 octaves, and the per-sample kernel that
+    serves more than 8 octaves.  The sampler is ONE function of position: whatever the memory layout, the walk is along z with the
+    same operation order, so the x-fastest, the z-fastest and the padded fill of the same points agree BIT FOR BIT."""
     import torch
     import volumetricterrain_amd as vt
     for kind in ("perlin3d", "fbm8"):
@@ -347,12 +347,19 @@ def test_density_sampler_matches_cpu_twin(ex, oracle_mod):
         want = oracle_mod.density_volume(kind, n)           # [x,y,z], x fastest
         d = torch.empty(dim ** 3, dtype=torch.float32, device="cuda")
         ex.density_fill_device(vt.density_params(kind, n), [[0, 0, 0]], (dim, dim, dim), (1, dim, dim * dim), 0, d.data_ptr())
-        got = d.cpu().numpy().reshape(dim, dim, dim).transpose(2, 1, 0)
+        got = d.cpu().numpy().reshape(dim, dim, dim).transpose(2, 1, 0).copy()
         assert np.abs(got - want).max() <= 2e-6
         # z fastest (a C# float[,,]): got[x, y, z] directly
         ex.density_fill_device(vt.density_params(kind, n), [[0, 0, 0]], (dim, dim, dim), (dim * dim, dim, 1), 0, d.data_ptr())
-        assert np.abs(d.cpu().numpy().reshape(dim, dim, dim) - want).max() <= 2e-6
-    # three ragged volumes at non-zero origins, padded rows (stride_y > dim_x): the y walk on an x-fastest layout
+        got_z = d.cpu().numpy().reshape(dim, dim, dim)
+        assert np.abs(got_z - want).max() <= 2e-6
+        assert np.array_equal(got_z.view(np.uint32), got.view(np.uint32)), "x-fastest and z-fastest fills differ in their bits"
+        # padded rows and slabs (stride_y > dim_x, stride_z > stride_y * dim_y): still the same bits
+        pd = torch.zeros((dim + 3) * (dim + 5) * dim, dtype=torch.float32, device="cuda")
+        ex.density_fill_device(vt.density_params(kind, n), [[0, 0, 0]], (dim, dim, dim), (1, dim + 3, (dim + 3) * (dim + 5)), 0, pd.data_ptr())
+        got_p = pd.cpu().numpy().reshape(dim, dim + 5, dim + 3)[:, :dim, :dim].transpose(2, 1, 0)
+        assert np.array_equal(got_p.view(np.uint32), got.view(np.uint32)), "padded and compact fills differ in their bits"
+    # three ragged volumes at non-zero origins, padded rows (stride_y > dim_x)
     dims, pad = (40, 300, 24), 48
     orgs = [(7, 100, 3), (512, 0, 77), (1000, 1700, 1999)]
     for octaves in (1, 3, 8, 11):
@@ -511,7 +518,9 @@ def test_max_size_single_grid_equals_chunked(ex, oracle_mod):
     T2 = ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, cdim, cdim * cdim), len(origins), cdim ** 3)
     tri_ptr, _, vc_ptr = ex.device_results()
     vc = ex.copy_u32(vc_ptr, 2 * len(origins)).reshape(-1, 2)
-    assert T2 == T and abs(T - 42485756) < 50000   # 42 485 756 with the per-sample sampler; the lattice-point zeros move by ~1e-7
+    # the sampler is one function of position (one walk, one operation order, whatever the layout or the chunking): an exact triangle count.
+    # (42 485 756 with the per-sample CPU twin's field: the samples that are zero in exact arithmetic -- the noise lattice points -- sit ~1e-7 off)
+    assert T2 == T == 42487270
     assert np.array_equal(vc[:, 1].astype(np.int64), per_chunk_whole)
     assert float_checksum(tri_ptr, T2) == sum_whole
 

@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
-"""Distils gpurun_out/prof_<tag>/ (made by tools/profile_round.sh) into profiles/<tag>/: kernel_stats.csv
-(rocprofv3 --stats of bench.py), kernel_stats_stream2048.csv, pmc_fetch_write.json (per-kernel FETCH_SIZE /
-WRITE_SIZE of the last dispatch, KiB as reported), fetch_calibration.json (the 40-byte-row gather: counter vs
-known bytes), the un-profiled bench lines, and profiles/pmc_traffic.json (HBM bytes per launch: WRITE_SIZE +
-FETCH_SIZE doubled -- the gfx950 correction of MI355X_MICROARCH.md for wide streaming reads; for the emit
-kernel's 40-byte rows that doubling is an upper bound, see fetch_calibration.json)."""
+"""Distils gpurun_out/prof_<tag>/ (made by tools/profile_round3.sh) into profiles/<tag>/: kernel_stats.csv
+(rocprofv3 --stats of bench.py), kernel_stats_stream2048.csv, pmc_requests_by_size.json (per-kernel memory-side
+requests by size of the last dispatch: exact read / write bytes), memory_ceilings.json + the raw tools/calib/mix2
+lines, the same-box A/B logs, the un-profiled bench lines, and profiles/pmc_traffic.json (HBM-side bytes per launch
+with the SHA-256 of the kernel sources they were measured on: bench.py reports `traffic` only while that still matches)."""
 import collections
 import csv
 import glob
@@ -64,51 +63,70 @@ def main():
                 open(os.path.join(dst, name), "w").write(lines[-1] if lines else "")
             else:
                 shutil.copy(f, os.path.join(dst, name))
-    fetch = last_per_kernel(first(os.path.join(src, "fetch", "*", "*_counter_collection.csv")), "FETCH_SIZE")
-    write = last_per_kernel(first(os.path.join(src, "write", "*", "*_counter_collection.csv")), "WRITE_SIZE")
-    json.dump({"FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB": write,
-               "note": "last dispatch of each kernel in a bench.py run; FETCH_SIZE raw = TCC_EA0_RDREQ x 64 B"},
-              open(os.path.join(dst, "pmc_fetch_write.json"), "w"), indent=1)
+    def sized_requests(rd_dir, wr_dir):
+        """Exact memory-side bytes per launch from the requests BY SIZE (last dispatch of each kernel): reads 32 / 64 / 128 B, writes 32 / 64 B."""
+        rd_csv = first(os.path.join(src, rd_dir, "*", "*_counter_collection.csv"))
+        wr_csv = first(os.path.join(src, wr_dir, "*", "*_counter_collection.csv"))
+        if not rd_csv or not wr_csv:
+            return {}
+        c = {name: last_per_kernel(rd_csv if "RDREQ" in name else wr_csv, name)
+             for name in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum")}
+        out = collections.OrderedDict()
+        for k in c["TCC_EA0_RDREQ_sum"]:
+            if not k.startswith("vtmc::"):
+                continue
+            r32, r64, r128 = (c["TCC_EA0_RDREQ_%s_sum" % w].get(k, 0.0) for w in ("32B", "64B", "128B"))
+            w_all, w64 = c["TCC_EA0_WRREQ_sum"].get(k, 0.0), c["TCC_EA0_WRREQ_64B_sum"].get(k, 0.0)
+            out[k] = {"read_requests": {"all": int(c["TCC_EA0_RDREQ_sum"][k]), "32B": int(r32), "64B": int(r64), "128B": int(r128)},
+                      "write_requests": {"all": int(w_all), "64B": int(w64)},
+                      "read_bytes": int(32 * r32 + 64 * r64 + 128 * r128), "write_bytes": int(64 * w64 + 32 * (w_all - w64)),
+                      "FETCH_SIZE_would_report_bytes": int(64 * c["TCC_EA0_RDREQ_sum"][k])}
+        return out
+
+    soup = sized_requests("req_rd", "req_wr")
+    json.dump({"kernels": soup, "note": "last dispatch of each kernel in a bench.py run, memory-side (TCC -> fabric) requests by size; read_bytes = 32 n32 + 64 n64 + 128 n128: "
+                                        "FETCH_SIZE (= all requests x 64 B) reports half of it when the requests are 128 bytes long -- the emit kernel's 40-byte rows are fetched "
+                                        "as whole 128-byte lines (98 % of its requests), which settles round 2's open question"},
+              open(os.path.join(dst, "pmc_requests_by_size.json"), "w"), indent=1)
     ist = first(os.path.join(src, "indexed", "*", "*_kernel_stats.csv"))
     if ist:
         shutil.copy(ist, os.path.join(dst, "kernel_stats_indexed.csv"))
-        try:
-            fi = last_per_kernel(first(os.path.join(src, "indexed_fetch", "*", "*_counter_collection.csv")), "FETCH_SIZE")
-            wi = last_per_kernel(first(os.path.join(src, "indexed_write", "*", "*_counter_collection.csv")), "WRITE_SIZE")
-            json.dump({"FETCH_SIZE_KiB_raw": fi, "WRITE_SIZE_KiB": wi, "note": "tools/ab_bench.py indexed=1: the <true, true> emit kernel and the <true> classify kernel are the indexed pipeline's"},
-                      open(os.path.join(dst, "pmc_fetch_write_indexed.json"), "w"), indent=1)
-        except Exception as e:   # noqa: BLE001
-            print("no indexed pmc:", e)
+        json.dump({"kernels": sized_requests("indexed_rd", "indexed_wr"), "note": "tools/ab_bench.py indexed=1: the <true, true, ...> emit kernel and the <true, ...> classify kernel are the indexed pipeline's"},
+                  open(os.path.join(dst, "pmc_requests_by_size_indexed.json"), "w"), indent=1)
     calib = {}
     try:
-        rows = json.load(open(os.path.join(src, "calib", "rows.json")))
-        mix = json.load(open(os.path.join(src, "calib", "mix.json")))
-        cf = last_per_kernel(first(os.path.join(src, "calib", "pmc", "*", "*_counter_collection.csv")), "FETCH_SIZE")
-        raw = list(cf.values())[-1] * 1024.0
-        calib = {"rows_kernel": rows, "mix_kernel": mix, "FETCH_SIZE_bytes_raw": raw,
-                 "raw_over_known_row_bytes": round(raw / rows["known_bytes"], 4),
-                 "doubled_would_imply_GBps": round(2 * raw / (rows["ms"] * 1e-3) / 1e9, 1),
-                 "reading": "40-byte rows, each read once from a 4.5 GB buffer: the raw counter is ~1.23 x the row bytes; doubling it (the "
-                            "guide's correction for 16-byte-per-lane streams) would mean more bytes per second than the chip can read, so for "
-                            "this access width the true fetch traffic lies between the raw counter and twice it"}
-        json.dump(calib, open(os.path.join(dst, "fetch_calibration.json"), "w"), indent=1)
+        rows = [json.loads(ln) for ln in open(os.path.join(src, "calib", "mix2.jsonl")) if ln.startswith("{")]
+        best = collections.OrderedDict()
+        for r in rows:
+            best[r["kernel"]] = max(best.get(r["kernel"], 0.0), r["TBps_med"])
+        shutil.copy(os.path.join(src, "calib", "mix2.jsonl"), os.path.join(dst, "mix2_calibration.jsonl"))
+        if os.path.exists(os.path.join(src, "calib", "chunks.jsonl")):
+            shutil.copy(os.path.join(src, "calib", "chunks.jsonl"), os.path.join(dst, "mix2_chunked_writes.jsonl"))
+        calib = {"best_median_TBps_by_mix": best,
+                 "note": "tools/calib/mix2: persistent grids of 1-8 workgroups per CU, 1-8 float4 in flight per lane, plain and non-temporal stores; the best median of every read : write mix"}
+        json.dump(calib, open(os.path.join(dst, "memory_ceilings.json"), "w"), indent=1)
     except Exception as e:   # noqa: BLE001
         print("no calibration:", e)
-    traffic = {}
-    for k in fetch:
-        if k.startswith("vtmc::"):
-            name = k.split("::")[1].split("<")[0]
-            traffic[name + "_hbm_bytes"] = int(2 * fetch[k] * 1024 + write.get(k, 0.0) * 1024)
-            traffic[name + "_fetch_bytes_raw"] = int(fetch[k] * 1024)
-            traffic[name + "_write_bytes"] = int(write.get(k, 0.0) * 1024)
-    traffic["source"] = ("profiles/%s/pmc_fetch_write.json; *_hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction for wide reads; an upper "
-                         "bound for the emit kernel's 40-byte rows, profiles/%s/fetch_calibration.json)" % (tag, tag))
+    for name in ("ab_emit_variants.txt", "ab_emit_ablation.txt"):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+    sys.path.insert(0, ROOT)
+    from volumetricterrain_amd import build as vt_build
+    traffic = {"kernel_source_sha256": vt_build.kernel_source_hash()}
+    for k, v in soup.items():
+        name = k.split("::")[1].split("<")[0]
+        traffic[name + "_hbm_bytes"] = v["read_bytes"] + v["write_bytes"]
+        traffic[name + "_read_bytes"] = v["read_bytes"]
+        traffic[name + "_write_bytes"] = v["write_bytes"]
+    traffic["source"] = ("profiles/%s/pmc_requests_by_size.json: memory-side requests by size (32 / 64 / 128 B), reads + writes, last dispatch of a bench.py run on the "
+                         "builder's lease; valid for the kernel sources with the recorded sha256 only" % tag)
     if calib:
-        traffic["mix_stream_ceiling_GBps"] = calib["mix_kernel"]["GBps_total"]
+        traffic["memory_ceilings_TBps"] = calib["best_median_TBps_by_mix"]
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print(open(os.path.join(dst, "kernel_stats.csv")).read())
     print(json.dumps(traffic, indent=1))
     print(json.dumps(calib, indent=1))
+    print("NOTE: profiles/pmc_traffic.json is valid for the CURRENT kernel sources only (sha256 recorded); re-run after any kernel change")
 
 
 if __name__ == "__main__":

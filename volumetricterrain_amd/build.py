@@ -24,6 +24,18 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared"
          "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
 
 
+def kernel_source_hash():
+    """SHA-256 over the kernel sources (csrc/*.hip, csrc/*.h): profiles/pmc_traffic.json records it next to the counter values it was
+    measured with, and bench.py reports `traffic` only while the sources still hash to the same value."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(CSRC, name), "rb").read())
+    return h.hexdigest()
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True

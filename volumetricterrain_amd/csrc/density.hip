@@ -99,12 +99,12 @@ __global__ __launch_bounds__(256) void density_generic_kernel(DensityLaunch dl, 
 // ----------------------------------------------------------------------------------------------
 // density_column_kernel -- the wave64 sampler (octaves <= 8).
 //
-// A lane owns one column of the volume and walks it along the WALK axis; the lanes of a workgroup are
-// 256 consecutive points of the plane spanned by the other two axes, enumerated along the stride-1
-// axis first.  WALK is the axis with the largest stride when that is z (x-fastest volumes: the lane
-// plane is then one contiguous slab of memory and every step of a workgroup writes 1 KB of it), else
-// y (the C# z-fastest layout).  What makes the sampler cheap is what is UNIFORM or CONSTANT along
-// the walk:
+// A lane owns one column of the volume and walks it along z; the lanes of a workgroup are 256
+// consecutive points of the (x, y) plane, x first.  For compact x-fastest volumes that plane is one
+// contiguous slab of memory and every step of a workgroup writes 1 KB of it; for the C# z-fastest
+// layout a column is contiguous instead and the values leave transposed through LDS (ZT).  The walk
+// axis never depends on the layout, so a sample is one function of its position: the same bits in
+// every layout.  What makes the sampler cheap is what is UNIFORM or CONSTANT along the walk:
 //   * everything that depends on the walk coordinate alone (lattice cell, fraction, fade weight,
 //     which octaves enter a new cell) is the same for every lane of every wave at that step: a small
 //     kernel writes it once per (volume, step) into a 128-byte row; a workgroup stages the rows of its
@@ -119,8 +119,7 @@ __global__ __launch_bounds__(256) void density_generic_kernel(DensityLaunch dl, 
 //     -- 5 VALU instructions per octave instead of 8 hashes + 8 gradients + 7 lerps;
 //   * the (alpha, beta) pairs are rebuilt only when the walk enters a new cell (wave-uniform: a bit of
 //     the row's mask word); stepping into the next cell re-uses the high face as the new low face, so
-//     one face = 8 LDS lookups (z walk: 4 hashes + 4 gradient vectors, the x-y part of the hash chain
-//     is constant along the walk; y walk: 2 + 2 + 4).
+//     one face = 4 LDS lookups of gradient vectors (the x-y part of the hash chain is constant along the walk).
 // Same noise definition as the per-sample kernel above and as oracle/density_ref.c; the lerp order
 // (lane axes first, walk axis last) and the fma contractions move results by a few 1e-7 (bar of the
 // twin test: 2e-6).
@@ -171,20 +170,28 @@ struct ColOct {
     unsigned key2;         // z walk: the same for (i,j) = 10, 11 -- byte offsets into s_g512 before the lattice row is added
 };
 
-// WALK = 1: along y, lane plane (x, z) or (z, x);  WALK = 2: along z, lane plane (x, y)
-template <int NOCT, int WALK>
-__global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl, const unsigned char *__restrict__ perm,
+// The walk is along z, lane plane (x, y), whatever the memory layout: a sample is one function of its position (round 2 also had a walk
+// along y for z-fastest and padded volumes: other axes interpolated first, last-bit differences, 26 of 5.4 M triangles on a 512^3 volume).
+// ZT: the volume is z-fastest in memory (the C# float[,,] order): a lane's column is contiguous, the lane plane is not.  The values of
+// kTrSteps steps go through LDS and leave as 16-byte stores along z (two lanes per column) instead of 64 four-byte stores to 64 lines a step.
+constexpr int kTrPitch = 258;   // 256 columns + 2: the transposed read is bank-conflict free
+constexpr int tr_steps(int noct) { return noct <= 4 ? 16 : 8; }   // steps per flush: 64-byte runs where the LDS budget allows (three workgroups per CU either way)
+template <int NOCT, bool ZT = false>
+__global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(DensityLaunch dl, const unsigned char *__restrict__ perm,
                                                               const int *__restrict__ origins, const float *__restrict__ rows,
                                                               float *__restrict__ out, int fast_is_z, int n_plane_wgs, int n_seg,
                                                               int seg_len, unsigned long long *__restrict__ signs)
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     __shared__ unsigned short s_p2[256];  // P(i) | P(i+1) << 8
-    __shared__ unsigned s_h2[WALK == 1 ? 256 : 1];   // y walk: byte offsets into s_grad of hash P(i) (low half) and P(i+1) (high half)
     __shared__ v4f s_grad[16];            // gradient of hash h as (gx, gy, gz, 0), components in {-1, 0, 1}
-    __shared__ v4f s_g512[WALK == 2 ? 512 : 1];      // z walk: gradient of hash P(i & 255), i = key byte + lattice row <= 511 -- one lookup per corner, no wrap
+    __shared__ v4f s_g512[512];      // gradient of hash P(i & 255), i = key byte + lattice row <= 511 -- one lookup per corner, no wrap
     __shared__ __attribute__((aligned(16))) float s_rows[kColSeg][kRowUsed];   // this segment's rows
     __shared__ float2 s_uv[NOCT][256];    // fade weights of the two lane axes, per octave and lane: constant along the walk, read back at a face rebuild
+    constexpr int kTrSteps = tr_steps(NOCT);
+    constexpr int kLanesPerCol = kTrSteps / 4;   // lanes that share a column's run of kTrSteps values (float4 each)
+    __shared__ float s_tr[ZT ? kTrSteps : 1][ZT ? kTrPitch : 1];   // ZT: the last kTrSteps values of every column
+    __shared__ long long s_col[ZT ? 256 : 1];                      // ZT: element offset of column c's first sample of this segment (-1: past the plane)
 
     const int tid = threadIdx.x;
     unsigned r = blockIdx.x;
@@ -192,15 +199,14 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
     r /= n_plane_wgs;
     const int seg = r % n_seg;
     const int vol = r / n_seg;
-    const int n_steps = WALK == 1 ? dl.dy : dl.dz;
+    const int n_steps = dl.dz;
     const int w_begin = seg * seg_len;
     const int w_count = min(seg_len, n_steps - w_begin);
-    const int ox = origins[3 * vol], oy = origins[3 * vol + 1], oz = origins[3 * vol + 2];
+    const int ox = origins[3 * vol], oy = origins[3 * vol + 1];   // the z origin enters through the rows (density_row_kernel)
 
     {   // tables
         const unsigned p0 = perm[tid], p1 = perm[(tid + 1) & 255];
         s_p2[tid] = (unsigned short)(p0 | (p1 << 8));
-        if (WALK == 1) s_h2[tid] = ((p0 & 15u) << 4) | (((p1 & 15u) << 4) << 16);
         if (tid < 16) {
             const int h = tid;   // gradf(): u = h<8 ? x : y;  v = h<4 ? y : (h==12||h==14 ? x : z);  (h&1 ? -u : u) + (h&2 ? -v : v)
             const float su = (h & 1) ? -1.f : 1.f, sv = (h & 2) ? -1.f : 1.f;
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
             const float g[3] = {(h < 8 ? su : 0.f) + (vx ? sv : 0.f), (h >= 8 ? su : 0.f) + (h < 4 ? sv : 0.f), (h >= 4 && !vx) ? sv : 0.f};
             s_grad[h] = v4f{g[0], g[1], g[2], 0.f};
         }
-        if (WALK == 2) {
+        {
             __syncthreads();   // s_grad
             s_g512[tid] = s_grad[p0 & 15u];
             s_g512[tid + 256] = s_grad[p0 & 15u];
@@ -227,25 +233,15 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
     bool live;
     {
         const long long q = (long long)pw * 256 + tid;
-        if (WALK == 1) {
-            const int dfast = fast_is_z ? dl.dz : dl.dx, dslow = fast_is_z ? dl.dx : dl.dz;
-            live = q < (long long)dfast * dslow;
-            const long long qc = live ? q : 0;
-            const int a = (int)(qc % dfast), c = (int)(qc / dfast);
-            i = fast_is_z ? c : a;
-            j = w_begin;
-            k = fast_is_z ? a : c;
-        } else {
-            live = q < (long long)dl.dx * dl.dy;
-            const long long qc = live ? q : 0;
-            i = (int)(qc % dl.dx);
-            j = (int)(qc / dl.dx);
-            k = w_begin;
-        }
+        live = q < (long long)dl.dx * dl.dy;
+        const long long qc = live ? q : 0;
+        i = (int)(qc % dl.dx);
+        j = (int)(qc / dl.dx);
+        k = w_begin;
     }
     // lane axes A, B: (x, z) for the y walk, (x, y) for the z walk
-    float pa = (float)(ox + i) * dl.frequency, pb = (WALK == 1 ? (float)(oz + k) : (float)(oy + j)) * dl.frequency;
-    const float lane_ramp = WALK == 1 ? 0.f : ((float)(oy + j) - dl.ramp_center) * dl.ramp_scale;
+    float pa = (float)(ox + i) * dl.frequency, pb = (float)(oy + j) * dl.frequency;
+    const float lane_ramp = ((float)(oy + j) - dl.ramp_center) * dl.ramp_scale;
 
     ColOct st[NOCT];
     float amp[NOCT];
@@ -258,10 +254,7 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
             st[o].ra = pa - fa;
             st[o].rb = pb - fb;
             const unsigned px = s_p2[A];   // P(X) | P(X+1) << 8
-            st[o].key2 = 0u;
-            if (WALK == 1) {
-                st[o].key = px | (B << 16);
-            } else {   // the x-y part of the hash chain is constant along a z walk
+            {   // the x-y part of the hash chain is constant along the z walk
                 const unsigned q0 = s_p2[((px & 255u) + B) & 255u], q1 = s_p2[((px >> 8) + B) & 255u];
                 st[o].key = ((q0 & 255u) << 4) | ((q0 >> 8) << 20);
                 st[o].key2 = ((q1 & 255u) << 4) | ((q1 >> 8) << 20);
@@ -282,18 +275,8 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
         float ra = s.ra, rb = s.rb;
         unsigned key = s.key, key2 = s.key2;
         asm volatile("" : "+v"(ra), "+v"(rb), "+v"(key), "+v"(key2));
-        const char *gb = reinterpret_cast<const char *>(s_grad);
         v4f g00, g01, g10, g11;   // g[a-corner][b-corner]
-        if (WALK == 1) {
-            const unsigned Z = key >> 16;
-            const unsigned p0 = s_p2[((key & 255u) + Wp) & 255u] & 255u;         // P(P(X) + Y)
-            const unsigned p1 = s_p2[(((key >> 8) & 255u) + Wp) & 255u] & 255u;  // P(P(X+1) + Y)
-            const unsigned h0 = s_h2[(p0 + Z) & 255u], h1 = s_h2[(p1 + Z) & 255u];
-            g00 = *reinterpret_cast<const v4f *>(gb + (h0 & 0xFFFFu));
-            g01 = *reinterpret_cast<const v4f *>(gb + (h0 >> 16));
-            g10 = *reinterpret_cast<const v4f *>(gb + (h1 & 0xFFFFu));
-            g11 = *reinterpret_cast<const v4f *>(gb + (h1 >> 16));
-        } else {
+        {
             const char *g5 = reinterpret_cast<const char *>(s_g512);
             const unsigned w16 = Wp << 4;   // wave-uniform
             g00 = *reinterpret_cast<const v4f *>(g5 + ((key & 0xFFFFu) + w16));
@@ -305,8 +288,8 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
         const float u = uv.x, v = uv.y;
         const float a0 = ra, a1 = ra - 1.0f, b0 = rb, b1 = rb - 1.0f;
         // gradient components: A is always x; B is z (y walk) or y (z walk); the walk component is the other one
-        auto gB = [](const v4f &g) { return WALK == 1 ? g.z : g.y; };
-        auto gW = [](const v4f &g) { return WALK == 1 ? g.y : g.z; };
+        auto gB = [](const v4f &g) { return g.y; };
+        auto gW = [](const v4f &g) { return g.z; };
         const float c00 = __builtin_fmaf(gB(g00), b0, g00.x * a0), c10 = __builtin_fmaf(gB(g10), b0, g10.x * a1);
         const float c01 = __builtin_fmaf(gB(g01), b1, g01.x * a0), c11 = __builtin_fmaf(gB(g11), b1, g11.x * a1);
         const float cu0 = __builtin_fmaf(u, c10 - c00, c00), cu1 = __builtin_fmaf(u, c11 - c01, c01);
@@ -316,9 +299,32 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
     };
 
     float *dst = out + vol * dl.sv + (long long)i * dl.sx + (long long)j * dl.sy + (long long)k * dl.sz;
-    const long long dst_step = WALK == 1 ? dl.sy : dl.sz;
+    const long long dst_step = dl.sz;
+    if constexpr (ZT) {
+        s_col[tid] = live ? vol * dl.sv + (long long)i * dl.sx + (long long)j * dl.sy + (long long)k * dl.sz : -1ll;
+        __syncthreads();
+    }
+    // ZT: steps [first, first + n) of this segment sit in s_tr[0..n): thread t writes quad t % kLanesPerCol of column t / kLanesPerCol + (256 / kLanesPerCol) * pass
+    auto flush_transposed = [&](int first, int n) {
+        typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < kLanesPerCol; ++pass) {
+            const int c = tid / kLanesPerCol + (256 / kLanesPerCol) * pass, q4 = 4 * (tid % kLanesPerCol);
+            const long long base = s_col[c];
+            if (base >= 0 && q4 < n && !(dl.ablate & 1)) {
+                float *p = out + base + first + q4;   // sz == 1
+                if (q4 + 4 <= n) {
+                    *reinterpret_cast<v4u *>(p) = v4u{s_tr[q4][c], s_tr[q4 + 1][c], s_tr[q4 + 2][c], s_tr[q4 + 3][c]};
+                } else {
+                    for (int r = 0; q4 + r < n; ++r) p[r] = s_tr[q4 + r][c];
+                }
+            }
+        }
+        __syncthreads();
+    };
     // sign volume: word ((vol * dz + k) * 4 n_plane_wgs + 4 pw + wave), bit = lane: the sign of plane point 256 pw + tid at step k
-    unsigned long long *sign_dst = (WALK == 2 && signs) ? signs + ((long long)vol * dl.dz + w_begin) * (4ll * n_plane_wgs) + 4 * pw + (tid >> 6) : nullptr;
+    unsigned long long *sign_dst = signs ? signs + ((long long)vol * dl.dz + w_begin) * (4ll * n_plane_wgs) + 4 * pw + (tid >> 6) : nullptr;
     float base_sum = 0.0f;   // sum of the low faces' constants a0 over the octaves, re-added in octave order whenever one of them changes
     for (int jj = 0; jj < w_count; ++jj) {
         // the step's row: five broadcast reads (every lane the same address)
@@ -356,10 +362,15 @@ __global__ __launch_bounds__(256, 4) void density_column_kernel(DensityLaunch dl
             sum = __builtin_fmaf(st[o].b0, t[o], sum);
             sum = __builtin_fmaf(fv[o], __builtin_fmaf(st[o].d, t[o], st[o].c), sum);
         }
-        const float value = sum - (WALK == 1 ? ma.x : lane_ramp);
-        if (live && (!(dl.ablate & 1) || sum == 1e30f)) *dst = value;   // ablate 1: diagnostics, no stores
-        dst += dst_step;
-        if (WALK == 2 && signs) {   // the sign volume (z walk only): one ballot per wave and step -- what the classify stage needs of this sample
+        const float value = sum - lane_ramp;
+        if constexpr (ZT) {
+            s_tr[jj % kTrSteps][tid] = value;
+            if (jj % kTrSteps == kTrSteps - 1 || jj == w_count - 1) flush_transposed(jj - jj % kTrSteps, jj % kTrSteps + 1);   // workgroup-uniform
+        } else {
+            if (live && (!(dl.ablate & 1) || sum == 1e30f)) *dst = value;   // ablate 1: diagnostics, no stores
+            dst += dst_step;
+        }
+        if (signs) {   // the sign volume (z walk only): one ballot per wave and step -- what the classify stage needs of this sample
             const unsigned long long m = __builtin_amdgcn_ballot_w64(value > 0.f);   // lanes past the plane's end own bits nobody reads
             if ((tid & 63) == 0) *sign_dst = m;
             sign_dst += 4 * n_plane_wgs;
@@ -382,31 +393,35 @@ hipError_t launch_density(const DensityLaunch &dl, const unsigned char *d_perm, 
     const int dfast = fast_is_z ? dl.dz : dl.dx;
     const int dslow = fast_is_z ? dl.dx : dl.dz;
     if (dl.octaves <= 8) {
-        // walk along z when the lane plane (x, y) is then contiguous in memory, else along y
-        const bool walk_z = dl.sx == 1 && dl.sy == dl.dx && dl.sz >= (long long)dl.dx * dl.dy;
-        const int n_steps = walk_z ? dl.dz : dl.dy;
-        const long long plane = walk_z ? (long long)dl.dx * dl.dy : (long long)dfast * dslow;
+        // ALWAYS along z, lanes over the (x, y) plane, whatever the memory layout: a sample is then one function of its position, the same
+        // bits for an x-fastest chunk, a padded volume and the C# z-fastest order (round 2 walked y for the latter two: the faces were
+        // interpolated over other axes first and the fields differed in the last bit -- 26 triangles of 5.4 M on a 512^3 volume).  The
+        // lane plane is contiguous memory for compact x-fastest volumes (every step of a workgroup writes 1 KB); for the z-fastest order a
+        // lane's column is contiguous instead and the stores of a step are 64 partial lines the L2 merges over the next steps.
+        const int n_steps = dl.dz;
+        const long long plane = (long long)dl.dx * dl.dy;
         const long long n_plane_wgs = (plane + 255) / 256;
         const int n_seg = (n_steps + kColSeg - 1) / kColSeg;
         const int seg_len = (n_steps + n_seg - 1) / n_seg;  // equal segments: every one pays the same two-face start-up
         const long long n_wgs = n_plane_wgs * n_seg * dl.n_volumes;
         const long long n_rows = (long long)dl.n_volumes * n_steps;
         if (n_wgs <= 0 || n_wgs > 0x7fffffffll || n_rows > 0x7fffffffll) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(density_row_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, dl, d_origins, walk_z ? 2 : 1,
+        hipLaunchKernelGGL(density_row_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, dl, d_origins, 2,
                            n_steps, seg_len, d_rows);
         // residency cap (tuning key "density_wgs_per_cu"): unused dynamic LDS leaves wave slots, registers and LDS to the kernels of
         // another stream -- the extract stages of the previous batch are HBM-bound, this kernel is ALU-bound
-        const size_t lds_static = 22272 + 2048 * (size_t)dl.octaves;
+        const bool zt = dl.sz == 1 && dl.sx != 1;   // z-fastest: transposed stores
+        const size_t lds_static = 22272 + 2048 * (size_t)dl.octaves + (zt ? sizeof(float) * tr_steps(dl.octaves) * kTrPitch + 2048 : 0);
         const size_t lds_want = dl.wgs_per_cu > 0 && dl.wgs_per_cu < 4 ? (size_t)(160 * 1024 / dl.wgs_per_cu - 1024) : 0;
         const size_t dyn = lds_want > lds_static ? (lds_want - lds_static) & ~(size_t)255 : 0;
 #define VTMC_COL(N)                                                                                                                   \
     case N:                                                                                                                           \
-        if (walk_z)                                                                                                                   \
-            hipLaunchKernelGGL((density_column_kernel<N, 2>), dim3((unsigned)n_wgs), dim3(256), dyn, stream, dl, d_perm, d_origins, d_rows, \
-                               d_out, fast_is_z, (int)n_plane_wgs, n_seg, seg_len, d_signs);                                        \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((density_column_kernel<N, 1>), dim3((unsigned)n_wgs), dim3(256), dyn, stream, dl, d_perm, d_origins, d_rows, \
+        if (zt)                                                                                                                       \
+            hipLaunchKernelGGL((density_column_kernel<N, true>), dim3((unsigned)n_wgs), dim3(256), dyn, stream, dl, d_perm, d_origins, d_rows, \
                                d_out, fast_is_z, (int)n_plane_wgs, n_seg, seg_len, nullptr);                                         \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((density_column_kernel<N, false>), dim3((unsigned)n_wgs), dim3(256), dyn, stream, dl, d_perm, d_origins, d_rows, \
+                               d_out, fast_is_z, (int)n_plane_wgs, n_seg, seg_len, d_signs);                                        \
         break;
         switch (dl.octaves) {   // the octave count is a template parameter: the eight octaves of a sample are straight-line code
             VTMC_COL(1) VTMC_COL(2) VTMC_COL(3) VTMC_COL(4) VTMC_COL(5) VTMC_COL(6) VTMC_COL(7) VTMC_COL(8)
