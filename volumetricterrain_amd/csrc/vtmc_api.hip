@@ -441,9 +441,16 @@ int32_t vtmc_extract_grid(vtmc_ctx *ctx, const float *grid, int32_t nx, int32_t 
                 const int32_t *p = block_list + 3 * (size_t)b;
                 const float *org = grid + 8 * ((int64_t)p[0] * stride_x + (int64_t)p[1] * stride_y + (int64_t)p[2] * stride_z);
                 float *t = tiles.data() + (size_t)b * VTMC_TILE_SAMPLES;
-                for (int iz = 0; iz < 10; ++iz)
-                    for (int iy = 0; iy < 10; ++iy)
-                        for (int ix = 0; ix < 10; ++ix) t[ix + 10 * iy + 100 * iz] = org[ix * stride_x + iy * stride_y + iz * stride_z];
+                // the innermost loop walks the grid axis with the smallest stride (z for a C# float[,,]): the reads stay in one or two cache lines
+                if (stride_z < stride_x) {
+                    for (int ix = 0; ix < 10; ++ix)
+                        for (int iy = 0; iy < 10; ++iy)
+                            for (int iz = 0; iz < 10; ++iz) t[ix + 10 * iy + 100 * iz] = org[ix * stride_x + iy * stride_y + iz * stride_z];
+                } else {
+                    for (int iz = 0; iz < 10; ++iz)
+                        for (int iy = 0; iy < 10; ++iy)
+                            for (int ix = 0; ix < 10; ++ix) t[ix + 10 * iy + 100 * iz] = org[ix * stride_x + iy * stride_y + iz * stride_z];
+                }
             }
             return vtmc_extract_blocks(ctx, tiles.data(), n_blocks, tri_count);
         }
