@@ -322,7 +322,7 @@ __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_v
 // ----------------------------------------------------------------------------------------------
 // cube edges with a sign change from the case (the reference's cornerToEdgeTable, VoxelTerrain.cs:489-507, as three nibble
 // operations: edges 0-3 / 4-7 are the low / high corner ring xor its rotation, edges 8-11 the two rings xor each other)
-__device__ __forceinline__ unsigned case_edge_mask_fwd(unsigned cs)
+__device__ __forceinline__ unsigned case_edge_mask(unsigned cs)
 {
     const unsigned n = cs & 15u, m = cs >> 4;
     const unsigned rn = (n ^ ((n >> 1) | (n << 3))) & 15u, rm = (m ^ ((m >> 1) | (m << 3))) & 15u;
@@ -358,11 +358,40 @@ __device__ __forceinline__ unsigned once_edge_entry(unsigned e)
 
 __device__ __forceinline__ void once_tables_init(OnceTables *t, int tid)   // 256 threads
 {
-    t->emask[tid] = (unsigned short)case_edge_mask_fwd((unsigned)tid);
+    t->emask[tid] = (unsigned short)case_edge_mask((unsigned)tid);
     if (tid < 12) t->edge[tid] = once_edge_entry((unsigned)tid);
     if (tid < 8) {
         const unsigned X = tid & 1, Y = (tid >> 1) & 1, Z = (tid >> 2) & 1;
         t->ownx[tid] = (unsigned short)((X * 0x202u) | (Y * 0x804u) | (Z * 0x090u) | ((X & Y) * 0x400u) | ((X & Z) * 0x020u) | ((Y & Z) * 0x040u));
+    }
+}
+
+// One mesh vertex from its descriptor (low lattice point x | y << 4 | z << 8, axis << 12): position along the edge
+// (MarchingCube.compute:128-133, from the edge's low endpoint) and the trilinear normal fetch of MarchingCube.compute:69-99, which on a
+// lattice edge is a 2-point lerp whose weight comes from the ROUNDED position.  rec = {position, normal}.
+template <bool FAST>
+__device__ __forceinline__ void eval_vertex(const float *tile, unsigned d, float (&rec)[6])
+{
+    const int c[3] = {(int)(d & 15u), (int)((d >> 4) & 15u), (int)((d >> 8) & 15u)};
+    const unsigned axis = d >> 12;
+    const int sk = axis == 0 ? 1 : (axis == 1 ? 10 : 100);
+    const int tl = c[0] + 10 * c[1] + 100 * c[2];
+    const float va = tile[tl], vb = tile[tl + sk];
+    // t lies in [0,1] (the endpoints differ in sign class); the 1-ulp v_rcp can land a hair outside: clamp it back
+    const float t = FAST ? __builtin_amdgcn_fmed3f(-va * __builtin_amdgcn_rcpf(vb - va), 0.0f, 1.0f) : (-va) / (vb - va);
+    const float ckf = (float)(axis == 0 ? c[0] : (axis == 1 ? c[1] : c[2]));
+    const float q = ckf + t;
+    const float fq = floorf(q);
+    const float w = q - fq;   // the weight comes from the ROUNDED position (MarchingCube.compute:71-72)
+    float g0[3], g1[3];
+    lattice_gradient(tile, tl + (int)(fq - ckf) * sk, g0);
+    lattice_gradient(tile, tl + (int)(ceilf(q) - ckf) * sk, g1);
+    normalise<FAST>(g0);
+    normalise<FAST>(g1);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        rec[a] = axis == (unsigned)a ? q : (float)c[a];
+        rec[3 + a] = FAST ? __builtin_fmaf(w, g1[a] - g0[a], g0[a]) : g0[a] + w * (g1[a] - g0[a]);
     }
 }
 
@@ -439,29 +468,11 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
     for (int s0 = 0; s0 < n_vert && !(ablate & 4); s0 += 64) {
         const int s = s0 + lane;
         if (s < n_vert) {
-            const unsigned d = vlist[s];
-            const int c[3] = {(int)(d & 15u), (int)((d >> 4) & 15u), (int)((d >> 8) & 15u)};
-            const unsigned axis = d >> 12;
-            const int sk = axis == 0 ? 1 : (axis == 1 ? 10 : 100);
-            const int tl = c[0] + 10 * c[1] + 100 * c[2];
-            const float va = tile[tl], vb = tile[tl + sk];
-            // t lies in [0,1] (the endpoints differ in sign class); the 1-ulp v_rcp can land a hair outside: clamp it back
-            const float t = FAST ? __builtin_amdgcn_fmed3f(-va * __builtin_amdgcn_rcpf(vb - va), 0.0f, 1.0f) : (-va) / (vb - va);
-            const float ckf = (float)(axis == 0 ? c[0] : (axis == 1 ? c[1] : c[2]));
-            const float q = ckf + t;
-            const float fq = floorf(q);
-            const float w = q - fq;   // the weight comes from the ROUNDED position (MarchingCube.compute:71-72)
-            float g0[3], g1[3];
-            lattice_gradient(tile, tl + (int)(fq - ckf) * sk, g0);
-            lattice_gradient(tile, tl + (int)(ceilf(q) - ckf) * sk, g1);
-            normalise<FAST>(g0);
-            normalise<FAST>(g1);
+            float r6[6];
+            eval_vertex<FAST>(tile, vlist[s], r6);
             float *rec = verts + s * 6;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                rec[a] = axis == (unsigned)a ? q : (float)c[a];
-                rec[3 + a] = FAST ? __builtin_fmaf(w, g1[a] - g0[a], g0[a]) : g0[a] + w * (g1[a] - g0[a]);
-            }
+            for (int a = 0; a < 6; ++a) rec[a] = r6[a];
         }
     }
     VTMC_WAVE_SYNC();
@@ -515,7 +526,8 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
 // t' = 1 - t differs from this one by rounding only (<= ~1e-6 in cell units, bar 1e-5).
 // ----------------------------------------------------------------------------------------------
 constexpr int kVertDwords = 6;   // 24-byte vertex record
-constexpr int kVlistCap = 512;   // vertex descriptors per evaluation window (a block rarely holds more)
+constexpr int kVlistCap = 256;   // vertex descriptors per evaluation window
+constexpr int kIdxFastVerts = 255;   // blocks with at most this many vertices number them in one byte per lattice edge (vtab)
 
 // owner-side id of a lattice edge: [axis * 4 + (o_u + 2 o_v)] -> cube edge, (u, v) = the two other axes in order
 constexpr u64 kOwnerEdge = 0x0ull | (2ull << 4) | (4ull << 8) | (6ull << 12) |            // x: (oy, oz)
@@ -526,27 +538,22 @@ struct __attribute__((aligned(16))) EmitLdsIdx {
     float tile[1000];
     union {
         unsigned slot[kSlotCap];          // pass 2: triangle slot -> cell | edge triple << 9
-        unsigned short vlist[kVlistCap];  // vertex phase: vertex id - window -> owner cell | cube edge << 9
+        unsigned short vlist[kVlistCap];  // vertex phase: vertex id - window -> low lattice point (x | y << 4 | z << 8) | axis << 12
     } q;
     unsigned short acell[512];      // active cells of the block, ascending cell id
-    unsigned cellmap[512];          // owner cell -> first vertex id | owned-edge mask << 16 (active cells only)
-    float stage[kStageTris * kVertDwords + 6];
-};   // 9424 bytes: with the two shared tables a workgroup takes 39.9 KB -- four per CU
-static_assert(sizeof(EmitLdsIdx) % 16 == 0 && offsetof(EmitLdsIdx, stage) % 16 == 0, "stage must stay 16-byte aligned");
+    union {
+        unsigned char vtab[2192];   // <= 255 vertices: lattice edge (axis * 729 + x + 9 y + 81 z) -> vertex id
+        unsigned cellmap[512];      // more: owner cell -> first vertex id | owned-edge mask << 16 (active cells only)
+    } m;
+    unsigned char acase[512];       // case of the k-th active cell (numbering -> pass 2)
+};   // 9264 bytes: with the shared tables a workgroup takes 39.6 KB -- four per CU
+static_assert(sizeof(EmitLdsIdx) % 16 == 0, "keeps the waves' blocks 16-byte aligned");
 
-// case of cell (cx, cy, cz) from the LDS tile (CollectTriNum.compute:27-51) and its cube edges with a sign
-// change (the reference's cornerToEdgeTable, VoxelTerrain.cs:489-507, as three nibble operations: edges 0-3 /
-// 4-7 are the low / high corner ring xor its rotation, edges 8-11 the two rings xor each other)
+// case of cell (cx, cy, cz) from the LDS tile (CollectTriNum.compute:27-51)
 __device__ __forceinline__ unsigned cell_case(const float *tile, unsigned cell)
 {
     const int t2 = (int)(cell & 7u) + 10 * (int)((cell >> 3) & 7u), cz = (int)(cell >> 6);
     return layer_nibble(tile, t2, cz) | (layer_nibble(tile, t2, cz + 1) << 4);
-}
-__device__ __forceinline__ unsigned case_edge_mask(unsigned cs)
-{
-    const unsigned n = cs & 15u, m = cs >> 4;
-    const unsigned rn = (n ^ ((n >> 1) | (n << 3))) & 15u, rm = (m ^ ((m >> 1) | (m << 3))) & 15u;
-    return rn | (rm << 4) | ((n ^ m) << 8);
 }
 
 // s_own[e * 8 + b7] for cube edge e of a cell whose coordinates equal 7 where b7 has a bit set: low byte = offset
@@ -562,13 +569,6 @@ __device__ __forceinline__ unsigned short owner_entry(unsigned e, unsigned b7)
     return (unsigned short)(delta | (eo << 8));
 }
 
-// cube edges a cell owns: always those at its corner 0; on the block's far faces also the ones beyond
-__device__ __forceinline__ unsigned owned_edges(int cx, int cy, int cz)
-{
-    const unsigned X = cx == 7, Y = cy == 7, Z = cz == 7;
-    return 0x109u | (X * 0x202u) | (Y * 0x804u) | (Z * 0x090u) | ((X & Y) * 0x400u) | ((X & Z) * 0x020u) | ((Y & Z) * 0x040u);
-}
-
 // exclusive wave prefix sum of a per-lane value in 0..15 from four ballots
 __device__ __forceinline__ unsigned wave_prefix4(unsigned n, unsigned &total)
 {
@@ -581,74 +581,66 @@ __device__ __forceinline__ unsigned wave_prefix4(unsigned n, unsigned &total)
     return lanes_below(m0) + 2u * lanes_below(m1) + 4u * lanes_below(m2) + 8u * lanes_below(m3);
 }
 
-// Stages `cnt` records of REC dwords (lane i holds record i) and streams them to out + d0 (dwords).  STAGE_DWORDS
-// is what the staging area holds: when a whole batch fits (the 12-byte index triples) it leaves in one round, else
-// through 33 slots in two rounds split at a 16-byte boundary of the output stream (see emit_flush2).
-template <int REC, int STAGE_DWORDS>
-__device__ __forceinline__ void stream_records(float *stage, const float (&rec)[REC], int cnt, float *__restrict__ out, size_t d0,
-                                               int lane, int ablate, int &vm_issued)
-{
-    const int sh = (int)(d0 & 3);
-    float *gal = out + (d0 - sh);
-    if (64 * REC + 3 <= STAGE_DWORDS) {
-        VTMC_WAVE_SYNC();
-        if (lane < cnt) {
-            float *d = stage + sh + lane * REC;
-#pragma unroll
-            for (int c = 0; c < REC; ++c) d[c] = rec[c];
-        }
-        VTMC_WAVE_SYNC();
-        stream_out_range<(64 * REC + 3 + 255) / 256>(stage, gal, sh, sh + cnt * REC, lane, ablate, vm_issued);
-        VTMC_WAVE_SYNC();
-        return;
-    }
-    const int split = 32 * REC + (sh ? 4 : 0), end = sh + cnt * REC;
-    for (int h = 0; h == 0 || cnt > 32 * h; ++h) {   // wave-uniform, at most two rounds
-        VTMC_WAVE_SYNC();
-        const int r = lane - 32 * h;
-        if (r >= 0 && r < kStageTris && lane < cnt) {
-            float *d = stage + sh + r * REC;
-#pragma unroll
-            for (int c = 0; c < REC; ++c) d[c] = rec[c];
-        }
-        VTMC_WAVE_SYNC();
-        const int lo = h == 0 ? sh : split, hi = (h == 0 && cnt > 32) ? split : end;
-        stream_out_range<(kStageTris * REC + 3 + 255) / 256>(stage - 32 * REC * h, gal, lo, hi, lane, ablate, vm_issued);
-    }
-    VTMC_WAVE_SYNC();
-}
-
+// Indexed output of one block.  Numbering (N), vertex evaluation (V), then triangle slots and indices (pass 2 + T):
+//   N : the active cells number the block's vertices in the canonical order (owner cell, then cube edge id): per cell the edges it
+//       owns with a sign change, one 4-ballot prefix sum per 64 cells, and per vertex a descriptor (low lattice point | axis) in
+//       `vlist`.  Blocks of at most 255 vertices (all but ~0.3 % on the benchmark fields) also leave the id of every lattice edge in
+//       the byte table `vtab`, so that a triangle lane finds a vertex with two table reads; larger blocks keep round 2's owner-cell map.
+//   V : one lane per vertex (eval_vertex), two 12-byte stores per lane straight from registers.
+//   T : one lane per triangle, one 12-byte store per lane: 64 lanes write 768 contiguous bytes, no staging.
 template <bool FAST>
-__device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_vert, const unsigned short *s_own, size_t tri_base,
-                                                   int tri_budget, size_t vert_base, int vert_budget, float *__restrict__ out_vertices,
-                                                   int *__restrict__ out_indices, int lane, int ablate, unsigned rowmask, int &vm_issued)
+__device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_vert, const unsigned short *s_own, const OnceTables *tb,
+                                                   size_t tri_base, int tri_budget, size_t vert_base, int vert_budget,
+                                                   float *__restrict__ out_vertices, int *__restrict__ out_indices, int lane, int ablate,
+                                                   unsigned rowmask, int &vm_issued)
 {
+    typedef float v3u __attribute__((ext_vector_type(3), aligned(4)));
+    typedef int i3u __attribute__((ext_vector_type(3), aligned(4)));
     const float *tile = L->tile;
-    // pass 1: compaction of the active cells (as the soup path, row masks included; cases are re-derived where needed)
+    // pass 1: compaction of the active cells (as the soup path, row masks included)
     const int n_act = compact_active_cells<false>(tile, L->acell, nullptr, lane, rowmask);
     VTMC_WAVE_SYNC();
+    const bool big = vert_budget > kIdxFastVerts;   // wave-uniform: the scan's vertex count of this block decides the numbering's form
 
-    // vertex numbering over the active cells, 64 per step: owned sign-change edges -> ids.  Descriptors
-    // of the ids below `window + kVlistCap` are queued on the way (window 0 here; later windows re-walk).
-    auto number_cells = [&](int window, bool write_map) {
+    // N: vertex numbering over the active cells, 64 per step.  Descriptors of the ids in [window, window + kVlistCap) are queued.
+    auto number_cells = [&](int window, bool first) {
         int vrun = 0;
         for (int c0 = 0; c0 < n_act; c0 += 64) {
             const int idx = c0 + lane;
             const bool valid = idx < n_act;
             const unsigned cell = valid ? L->acell[idx] : 0u;
-            const int cx = cell & 7, cy = (cell >> 3) & 7, cz = cell >> 6;
-            unsigned owned = valid ? (case_edge_mask(cell_case(tile, cell)) & owned_edges(cx, cy, cz)) : 0u;   // the case again from the tile: cheaper than 512 bytes of LDS
+            const unsigned cs = valid ? cell_case(tile, cell) : 0u;
+            if (first && valid) L->acase[idx] = (unsigned char)cs;
+            const unsigned cx = cell & 7u, cy = (cell >> 3) & 7u, cz = cell >> 6;
+            const unsigned b7 = (unsigned)(cx == 7u) | ((unsigned)(cy == 7u) << 1) | ((unsigned)(cz == 7u) << 2);
+            const unsigned owned = valid ? (tb->emask[cs] & (0x109u | tb->ownx[b7])) : 0u;
+            const unsigned desc = cx | (cy << 4) | (cz << 8);
+            const unsigned cell9 = cx + 9u * cy + 81u * cz;
             unsigned step_total;
-            const unsigned pre = wave_prefix4((unsigned)__builtin_popcount(owned), step_total);
-            int id = vrun + (int)pre;
-            if (valid && write_map) L->cellmap[cell] = (unsigned)id | (owned << 16);
-            while (__builtin_amdgcn_ballot_w64(owned != 0u)) {   // a lane owns 1-3 vertices as a rule, 12 at most
-                if (owned) {
-                    const unsigned e = (unsigned)__builtin_ctz(owned);
+            const int id0 = vrun + (int)wave_prefix4((unsigned)__builtin_popcount(owned), step_total);
+            if (big && first && valid) L->m.cellmap[cell] = (unsigned)id0 | (owned << 16);
+            // the three edges at the cell's corner 0 (cube edges 0, 3, 8): their rank among the cell's owned edges is a popcount
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const unsigned bit = a == 0 ? 0u : (a == 1 ? 3u : 8u);
+                if ((owned >> bit) & 1u) {
+                    const int id = id0 + __builtin_popcount(owned & ((1u << bit) - 1u));
                     const int q = id - window;
-                    if (q >= 0 && q < kVlistCap) L->q.vlist[q] = (unsigned short)(cell | (e << 9));
-                    ++id;
-                    owned &= owned - 1u;
+                    if (q >= 0 && q < kVlistCap) L->q.vlist[q] = (unsigned short)(desc | ((unsigned)a << 12));
+                    if (!big) L->m.vtab[729 * a + cell9] = (unsigned char)id;
+                }
+            }
+            // the far-face edges of a boundary cell, each round every lane's next one
+            unsigned ex = owned & ~0x109u;
+            while (__builtin_amdgcn_ballot_w64(ex != 0u)) {
+                if (ex) {
+                    const unsigned e = (unsigned)__builtin_ctz(ex);
+                    const unsigned ed = tb->edge[e];
+                    const int id = id0 + __builtin_popcount(owned & ((1u << e) - 1u));
+                    const int q = id - window;
+                    if (q >= 0 && q < kVlistCap) L->q.vlist[q] = (unsigned short)(desc + (ed & 0xFFFFu));
+                    if (!big) L->m.vtab[cell9 + (ed >> 16)] = (unsigned char)id;
+                    ex &= ex - 1u;
                 }
             }
             vrun += (int)step_total;
@@ -658,68 +650,55 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
     int n_vert = (ablate & 64) ? 0 : number_cells(0, true);
     if (n_vert > vert_budget) n_vert = vert_budget;  // never outside the block's slice of the vertex buffer
 
-    // vertex evaluation: one lane per vertex, from the edge's low endpoint
+    // V: one lane per vertex, from the edge's low endpoint; position and normal leave as two 12-byte stores per lane
     for (int window = 0; window < n_vert; window += kVlistCap) {
         if (window > 0) number_cells(window, false);
         VTMC_WAVE_SYNC();
         const int n_w = n_vert - window < kVlistCap ? n_vert - window : kVlistCap;
         for (int s0 = 0; s0 < n_w && !(ablate & 16); s0 += 64) {
             const int s = s0 + lane;
-            float rec[kVertDwords] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (s < n_w) {
-                const unsigned ent = L->q.vlist[s];
-                const int cell = ent & 511u;
-                const unsigned g = (unsigned)(kEdgeGeom >> (5u * (ent >> 9))) & 31u;
-                const unsigned axis = g >> 3, lowoff = g & 7u & ~(1u << axis);   // endpoint a's offsets, the axis bit cleared: the low point
-                const int c[3] = {(cell & 7) + (int)(lowoff & 1u), ((cell >> 3) & 7) + (int)((lowoff >> 1) & 1u), (cell >> 6) + (int)(lowoff >> 2)};
-                const int sk = axis == 0 ? 1 : (axis == 1 ? 10 : 100);
-                const int tl = c[0] + 10 * c[1] + 100 * c[2];
-                const float va = tile[tl], vb = tile[tl + sk];
-                const float t = FAST ? __builtin_amdgcn_fmed3f(-va * __builtin_amdgcn_rcpf(vb - va), 0.0f, 1.0f) : (-va) / (vb - va);
-                const int ck = axis == 0 ? c[0] : (axis == 1 ? c[1] : c[2]);
-                const float q = (float)ck + t;
-                const float fq = floorf(q);
-                const float w = q - fq;
-                float g0[3], g1[3];
-                lattice_gradient(tile, tl + ((int)fq - ck) * sk, g0);
-                lattice_gradient(tile, tl + ((int)ceilf(q) - ck) * sk, g1);
-                normalise<FAST>(g0);
-                normalise<FAST>(g1);
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    rec[a] = axis == (unsigned)a ? q : (float)c[a];
-                    rec[3 + a] = FAST ? __builtin_fmaf(w, g1[a] - g0[a], g0[a]) : g0[a] + w * (g1[a] - g0[a]);
+                float rec[kVertDwords];
+                eval_vertex<FAST>(tile, L->q.vlist[s], rec);
+                float *p = out_vertices + (vert_base + (size_t)(window + s)) * kVertDwords;
+                if (!(ablate & 1)) {
+                    *reinterpret_cast<v3u *>(p) = v3u{rec[0], rec[1], rec[2]};
+                    *reinterpret_cast<v3u *>(p + 3) = v3u{rec[3], rec[4], rec[5]};
                 }
             }
-            const int cnt = n_w - s0 < 64 ? n_w - s0 : 64;
-            stream_records<kVertDwords, kStageTris * kVertDwords + 6>(L->stage, rec, cnt, out_vertices, (vert_base + (size_t)(window + s0)) * kVertDwords, lane, ablate, vm_issued);
+            vm_issued += (ablate & 1) ? 0 : 2;   // issued for certain: lane 0 of the batch has a vertex
         }
         VTMC_WAVE_SYNC();
     }
 
-    // pass 2 + index flush: triangle slots, 64 active cells per step; a triangle lane finds each of its
-    // three edges' owner cell and reads the id from the cell map
+    // pass 2 + T: triangle slots, 64 active cells per step; a triangle lane finds each of its three vertices in the lattice-edge table
+    // (or, in a block of more than 255 vertices, through its edge's owner cell) and writes its index triple from registers
     auto flush = [&](int pending, size_t base) {
         VTMC_WAVE_SYNC();
         if (ablate & 32) pending = 0;
         for (int s0 = 0; s0 < pending; s0 += 64) {
             const int s = s0 + lane;
-            float rec[3] = {0.f, 0.f, 0.f};
             if (s < pending) {
                 const unsigned sc = L->q.slot[s];
-                const int cell = sc & 511u;
-                const unsigned trip = sc >> 9;
-                const unsigned b7 = (unsigned)((cell & 7) == 7) | ((unsigned)(((cell >> 3) & 7) == 7) << 1) | ((unsigned)((cell >> 6) == 7) << 2);
+                const unsigned cell = sc & 511u, trip = sc >> 9;
                 const unsigned e[3] = {trip & 15u, (trip >> 8) & 15u, (trip >> 4) & 15u};  // winding swap, MarchingCube.compute:147-157
+                int id[3];
+                if (!big) {
+                    const unsigned cell9 = (cell & 7u) + 9u * ((cell >> 3) & 7u) + 81u * (cell >> 6);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const unsigned ow = s_own[e[k] * 8u + b7];                 // owner cell offset | owner-side edge id << 8
-                    const unsigned vm = L->cellmap[cell + (int)(ow & 0xFFu)];
-                    rec[k] = __int_as_float((int)((vm & 0xFFFFu) + (unsigned)__builtin_popcount((vm >> 16) & ((1u << (ow >> 8)) - 1u))));
+                    for (int k = 0; k < 3; ++k) id[k] = (int)L->m.vtab[cell9 + (tb->edge[e[k]] >> 16)];
+                } else {
+                    const unsigned b7 = (unsigned)((cell & 7u) == 7u) | ((unsigned)(((cell >> 3) & 7u) == 7u) << 1) | ((unsigned)((cell >> 6) == 7u) << 2);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const unsigned ow = s_own[e[k] * 8u + b7];                 // owner cell offset | owner-side edge id << 8
+                        const unsigned vm = L->m.cellmap[cell + (ow & 0xFFu)];
+                        id[k] = (int)((vm & 0xFFFFu) + (unsigned)__builtin_popcount((vm >> 16) & ((1u << (ow >> 8)) - 1u)));
+                    }
                 }
+                if (!(ablate & 1)) *reinterpret_cast<i3u *>(out_indices + (base + (size_t)s) * 3) = i3u{id[0], id[1], id[2]};
             }
-            const int cnt = pending - s0 < 64 ? pending - s0 : 64;
-            stream_records<3, kStageTris * kVertDwords + 6>(L->stage, rec, cnt, reinterpret_cast<float *>(out_indices), (base + (size_t)s0) * 3, lane, ablate, vm_issued);
+            vm_issued += (ablate & 1) ? 0 : 1;
         }
     };
     int pending = 0;
@@ -734,7 +713,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
         const int idx = c0 + lane;
         const bool valid = idx < n_act;
         const unsigned cell = valid ? L->acell[idx] : 0u;
-        const u64 vw = valid ? s_vert[cell_case(tile, cell)] : 0ull;
+        const u64 vw = valid ? s_vert[(ablate & 64) ? cell_case(tile, cell) : (unsigned)L->acase[idx]] : 0ull;
         const unsigned n = (unsigned)(vw >> 60);
         unsigned step_total;
         const unsigned pre_n = wave_prefix3(n, step_total);

@@ -125,13 +125,13 @@ __global__ __launch_bounds__(256, ONCE ? 3 : 4) void emit_kernel(BlockSpace sp, 
     __shared__ Lds s_lds[kWavesPerWg];
     __shared__ u64 s_vert[256];
     struct NoTables { unsigned char unused; };
-    __shared__ typename std::conditional<ONCE, OnceTables, NoTables>::type s_once[1];
+    __shared__ typename std::conditional<ONCE || INDEXED, OnceTables, NoTables>::type s_once[1];
     __shared__ unsigned short s_own[INDEXED ? 96 : 1];   // (cube edge, which coordinates are 7) -> owner cell offset | owner-side edge id
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     s_vert[threadIdx.x] = tb.vert_packed[threadIdx.x];
     if (INDEXED && threadIdx.x < 96) s_own[threadIdx.x] = owner_entry(threadIdx.x >> 3, threadIdx.x & 7u);
-    if constexpr (ONCE) once_tables_init(&s_once[0], threadIdx.x);
+    if constexpr (ONCE || INDEXED) once_tables_init(&s_once[0], threadIdx.x);
 #ifdef VTMC_DEBUG_POISON_LDS  // diagnostic build: NaN-fill LDS so any read of a never-written word shows up in the output
     for (unsigned i = threadIdx.x; i < sizeof(s_lds) / 4; i += 256) reinterpret_cast<unsigned *>(s_lds)[i] = 0x7FC00000u;
 #endif
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, ONCE ? 3 : 4) void emit_kernel(BlockSpace sp, 
             VTMC_WAVE_SYNC();
             const int budget = (int)(cur.tri_end - cur.tri_base);
             if constexpr (INDEXED)
-                emit_block_indexed<FAST>(L, s_vert, s_own, (size_t)cur.tri_base, budget, (size_t)cur.vert_base, (int)(cur.vert_end - cur.vert_base), out,
+                emit_block_indexed<FAST>(L, s_vert, s_own, &s_once[0], (size_t)cur.tri_base, budget, (size_t)cur.vert_base, (int)(cur.vert_end - cur.vert_base), out,
                                          out_indices, lane, ablate, cur.mask, vm_issued);
             else if constexpr (ONCE)
                 emit_block_once<FAST>(L, s_vert, &s_once[0], (size_t)cur.tri_base, budget, cur.b, out, lane, ablate, cur.mask, vm_issued);
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, ONCE ? 3 : 4) void emit_kernel(BlockSpace sp, 
         VTMC_WAVE_SYNC();
 
         if constexpr (INDEXED)
-            emit_block_indexed<FAST>(L, s_vert, s_own, tri_base, budget, (size_t)voffsets[b], (int)(voffsets[b + 1] - voffsets[b]), out,
+            emit_block_indexed<FAST>(L, s_vert, s_own, &s_once[0], tri_base, budget, (size_t)voffsets[b], (int)(voffsets[b + 1] - voffsets[b]), out,
                                      out_indices, lane, ablate, mask, vm_unused);
         else if constexpr (ONCE)
             emit_block_once<FAST>(L, s_vert, &s_once[0], tri_base, budget, b, out, lane, ablate, mask, vm_unused);
