@@ -228,17 +228,34 @@ __device__ __forceinline__ void emit_flush2(EmitLds2 *L, int pending, size_t tri
     }
 }
 
-// Pass 1 of a block: cases (CollectTriNum.compute:48-51) of the cell layers that can hold triangles and
-// compaction of the active cells, ascending cell id, one ballot per layer.  rowmask bits 0-7 / 8-15: the y /
-// z layers with such cells (0xFFFF = unknown): a dead z layer costs nothing (wave-uniform skip), and the
-// sample plane between two live layers is classified once.  WRITE_CASES also stores every live cell's case.
-template <bool WRITE_CASES>
-__device__ __forceinline__ int compact_active_cells(const float *tile, unsigned short *acell, unsigned char *cases, int lane, unsigned rowmask)
+// case of cell (cx, cy, cz) from the LDS tile (CollectTriNum.compute:27-51)
+__device__ __forceinline__ unsigned cell_case(const float *tile, unsigned cell)
 {
-    const int t0 = (lane & 7) + 10 * (lane >> 3);
-    const bool y_live = (rowmask >> (lane >> 3)) & 1u;
+    const int t2 = (int)(cell & 7u) + 10 * (int)((cell >> 3) & 7u), cz = (int)(cell >> 6);
+    return layer_nibble(tile, t2, cz) | (layer_nibble(tile, t2, cz + 1) << 4);
+}
+
+// Pass 1 of a block: compaction of the cells that hold triangles, ascending cell id, IN MASK SPACE.  A lane compares the four samples
+// under its cell column (x, y) of a sample layer with 0 (strict '>' as CollectTriNum.compute:50; NaN => outside); each v_cmp leaves the
+// wave's 64 answers in a scalar register pair, so "all eight corners equal?" (case 0x00 or 0xFF, CollectTriNum.compute:48-51: no
+// triangles) is four scalar or / and per sample layer and three per cell layer, the active cells of a layer are the EXEC mask of its
+// compaction store, and no lane ever assembles a case it will not use -- 4 vector instructions per sample layer + 4 per live cell layer
+// instead of ~20 per cell layer.  The case of an active cell is derived where it is needed (cell_case).
+// rowmask bits 0-7 / 8-15: the y / z layers that hold such cells (0xFFFF = unknown): a dead z layer costs nothing (wave-uniform skip),
+// and the sample plane between two live layers is classified once.
+__device__ __forceinline__ int compact_active_cells(const float *tile, unsigned short *acell, int lane, unsigned rowmask)
+{
+    const float *p0 = tile + (lane & 7) + 10 * (lane >> 3);
+    const u64 y_live = __builtin_amdgcn_ballot_w64(((rowmask >> (lane >> 3)) & 1u) != 0u);
+    auto layer_masks = [&](int z, u64 &any, u64 &all) {   // over the 2 x 2 samples of sample layer z under every cell column
+        const float *p = p0 + 100 * z;
+        const u64 a = __builtin_amdgcn_ballot_w64(p[0] > 0.f), b = __builtin_amdgcn_ballot_w64(p[1] > 0.f);
+        const u64 c = __builtin_amdgcn_ballot_w64(p[10] > 0.f), d = __builtin_amdgcn_ballot_w64(p[11] > 0.f);
+        any = (a | b) | (c | d);
+        all = (a & b) & (c & d);
+    };
     int n_act = 0;
-    unsigned lo = 0;
+    u64 any_lo = 0, all_lo = 0;
     bool have_lo = false;
 #pragma unroll
     for (int z = 0; z < 8; ++z) {
@@ -246,17 +263,15 @@ __device__ __forceinline__ int compact_active_cells(const float *tile, unsigned 
             have_lo = false;
             continue;
         }
-        if (!have_lo) lo = layer_nibble(tile, t0, z);
-        const unsigned hi = layer_nibble(tile, t0, z + 1);
-        const unsigned cs = lo | (hi << 4);
-        lo = hi;
+        if (!have_lo) layer_masks(z, any_lo, all_lo);
+        u64 any_hi, all_hi;
+        layer_masks(z + 1, any_hi, all_hi);
+        const u64 act = (any_lo | any_hi) & ~(all_lo & all_hi) & y_live;   // not all eight corners equal, in a live y layer
+        any_lo = any_hi;
+        all_lo = all_hi;
         have_lo = true;
-        const int cell = 64 * z + lane;
-        if (WRITE_CASES) cases[cell] = (unsigned char)cs;
-        const bool act = ((cs + 1u) & 0xFFu) > 1u && y_live;  // neither 0x00 nor 0xFF, in a live y layer
-        const u64 m = __builtin_amdgcn_ballot_w64(act);
-        if (act) acell[n_act + (int)lanes_below(m)] = (unsigned short)cell;
-        n_act += __builtin_popcountll(m);
+        if (__builtin_amdgcn_inverse_ballot_w64(act)) acell[n_act + (int)lanes_below(act)] = (unsigned short)(64 * z + lane);
+        n_act += __builtin_popcountll(act);
     }
     return n_act;
 }
@@ -272,7 +287,7 @@ __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_v
                                                      int block_id, float *__restrict__ out, int lane, int ablate,
                                                      unsigned rowmask, int &vm_issued)
 {
-    const int n_act = compact_active_cells<true>(L->tile, L->acell, L->cases, lane, rowmask);   // pass 1
+    const int n_act = compact_active_cells(L->tile, L->acell, lane, rowmask);   // pass 1
     VTMC_WAVE_SYNC();
 
     // pass 2: triangle slots, 64 active cells per step
@@ -288,7 +303,7 @@ __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_v
         const int idx = c0 + lane;
         const bool valid = idx < n_act;
         const unsigned cell = valid ? L->acell[idx] : 0u;
-        const u64 vw = valid ? s_vert[L->cases[cell]] : 0ull;  // fifteen 4-bit edge ids + the count in the top nibble
+        const u64 vw = valid ? s_vert[cell_case(L->tile, cell)] : 0ull;  // fifteen 4-bit edge ids + the count in the top nibble
         const unsigned n = (unsigned)(vw >> 60);
         unsigned step_total;
         const unsigned pre_n = wave_prefix3(n, step_total);
@@ -404,7 +419,7 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
         return;
     }
     const float *tile = L->c.tile;
-    const int n_act = compact_active_cells<true>(tile, L->c.acell, L->c.cases, lane, rowmask);   // pass 1
+    const int n_act = compact_active_cells(tile, L->c.acell, lane, rowmask);   // pass 1
     VTMC_WAVE_SYNC();
     unsigned short *vlist = L->vlist();
     unsigned char *vtab = L->vtab();
@@ -415,7 +430,7 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
         const int idx = c0 + lane;
         const bool valid = idx < n_act;
         const unsigned cell = valid ? L->c.acell[idx] : 0u;
-        const unsigned cs = valid ? L->c.cases[cell] : 0u;   // case 0: no edges, no triangles
+        const unsigned cs = valid ? cell_case(tile, cell) : 0u;   // case 0: no edges, no triangles
         const u64 vw = s_vert[cs];
         const unsigned em = tb->emask[cs];
         const unsigned cx = cell & 7u, cy = (cell >> 3) & 7u, cz = cell >> 6;
@@ -545,16 +560,10 @@ struct __attribute__((aligned(16))) EmitLdsIdx {
         unsigned char vtab[2192];   // <= 255 vertices: lattice edge (axis * 729 + x + 9 y + 81 z) -> vertex id
         unsigned cellmap[512];      // more: owner cell -> first vertex id | owned-edge mask << 16 (active cells only)
     } m;
-    unsigned char acase[512];       // case of the k-th active cell (numbering -> pass 2)
+    unsigned char cases[512];       // case of every active cell (numbering -> pass 2)
 };   // 9264 bytes: with the shared tables a workgroup takes 39.6 KB -- four per CU
 static_assert(sizeof(EmitLdsIdx) % 16 == 0, "keeps the waves' blocks 16-byte aligned");
 
-// case of cell (cx, cy, cz) from the LDS tile (CollectTriNum.compute:27-51)
-__device__ __forceinline__ unsigned cell_case(const float *tile, unsigned cell)
-{
-    const int t2 = (int)(cell & 7u) + 10 * (int)((cell >> 3) & 7u), cz = (int)(cell >> 6);
-    return layer_nibble(tile, t2, cz) | (layer_nibble(tile, t2, cz + 1) << 4);
-}
 
 // s_own[e * 8 + b7] for cube edge e of a cell whose coordinates equal 7 where b7 has a bit set: low byte = offset
 // of the OWNER cell's id from the cell's, high byte = the edge's id as the owner sees it (kOwnerEdge)
@@ -598,7 +607,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
     typedef int i3u __attribute__((ext_vector_type(3), aligned(4)));
     const float *tile = L->tile;
     // pass 1: compaction of the active cells (as the soup path, row masks included)
-    const int n_act = compact_active_cells<false>(tile, L->acell, nullptr, lane, rowmask);
+    const int n_act = compact_active_cells(tile, L->acell, lane, rowmask);
     VTMC_WAVE_SYNC();
     const bool big = vert_budget > kIdxFastVerts;   // wave-uniform: the scan's vertex count of this block decides the numbering's form
 
@@ -610,7 +619,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
             const bool valid = idx < n_act;
             const unsigned cell = valid ? L->acell[idx] : 0u;
             const unsigned cs = valid ? cell_case(tile, cell) : 0u;
-            if (first && valid) L->acase[idx] = (unsigned char)cs;
+            if (first && valid) L->cases[cell] = (unsigned char)cs;   // for pass 2
             const unsigned cx = cell & 7u, cy = (cell >> 3) & 7u, cz = cell >> 6;
             const unsigned b7 = (unsigned)(cx == 7u) | ((unsigned)(cy == 7u) << 1) | ((unsigned)(cz == 7u) << 2);
             const unsigned owned = valid ? (tb->emask[cs] & (0x109u | tb->ownx[b7])) : 0u;
@@ -625,9 +634,13 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
                 const unsigned bit = a == 0 ? 0u : (a == 1 ? 3u : 8u);
                 if ((owned >> bit) & 1u) {
                     const int id = id0 + __builtin_popcount(owned & ((1u << bit) - 1u));
-                    const int q = id - window;
-                    if (q >= 0 && q < kVlistCap) L->q.vlist[q] = (unsigned short)(desc | ((unsigned)a << 12));
-                    if (!big) L->m.vtab[729 * a + cell9] = (unsigned char)id;
+                    if (!big) {   // at most 255 vertices: one window, every id has its byte
+                        L->q.vlist[id & 255] = (unsigned short)(desc | ((unsigned)a << 12));   // & 255: a count mismatch could never write outside the list
+                        L->m.vtab[729 * a + cell9] = (unsigned char)id;
+                    } else {
+                        const int q = id - window;
+                        if (q >= 0 && q < kVlistCap) L->q.vlist[q] = (unsigned short)(desc | ((unsigned)a << 12));
+                    }
                 }
             }
             // the far-face edges of a boundary cell, each round every lane's next one
@@ -637,9 +650,13 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
                     const unsigned e = (unsigned)__builtin_ctz(ex);
                     const unsigned ed = tb->edge[e];
                     const int id = id0 + __builtin_popcount(owned & ((1u << e) - 1u));
-                    const int q = id - window;
-                    if (q >= 0 && q < kVlistCap) L->q.vlist[q] = (unsigned short)(desc + (ed & 0xFFFFu));
-                    if (!big) L->m.vtab[cell9 + (ed >> 16)] = (unsigned char)id;
+                    if (!big) {
+                        L->q.vlist[id & 255] = (unsigned short)(desc + (ed & 0xFFFFu));
+                        L->m.vtab[cell9 + (ed >> 16)] = (unsigned char)id;
+                    } else {
+                        const int q = id - window;
+                        if (q >= 0 && q < kVlistCap) L->q.vlist[q] = (unsigned short)(desc + (ed & 0xFFFFu));
+                    }
                     ex &= ex - 1u;
                 }
             }
@@ -713,7 +730,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
         const int idx = c0 + lane;
         const bool valid = idx < n_act;
         const unsigned cell = valid ? L->acell[idx] : 0u;
-        const u64 vw = valid ? s_vert[(ablate & 64) ? cell_case(tile, cell) : (unsigned)L->acase[idx]] : 0ull;
+        const u64 vw = valid ? s_vert[(ablate & 64) ? cell_case(tile, cell) : (unsigned)L->cases[cell]] : 0ull;   // ablate 64 (diagnostics) skips the numbering that leaves the cases
         const unsigned n = (unsigned)(vw >> 60);
         unsigned step_total;
         const unsigned pre_n = wave_prefix3(n, step_total);
