@@ -60,6 +60,7 @@ def test_stream_config_line():
     assert j["n_gpus"] == 1 and j["config"]["chunks_per_gpu"] == 8 and j["config"]["kind"] == "fbm8"
     assert j["value"] > 0 and j["triangles_total"] > 0
     assert j["roofline"]["kernel"] in ("density_column_kernel", "classify_dense_kernel", "emit_kernel")
+    assert j["roofline"]["bound"] == ("valu" if j["roofline"]["kernel"] == "density_column_kernel" else "hbm")   # the sampler is bound by vector issue
     assert j["sampler_valu"]["frac"] > 0 and j["overlap_gain"] > 0
 
 
