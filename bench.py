@@ -69,11 +69,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chunks", type=int, default=32, help="chunks the CPU oracle is timed on")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0: physical cores in this process's CPU share, at most 16 per GPU)")
-    ap.add_argument("--pipeline", type=int, default=None, choices=[1, 2],
-                    help="grid1024: steps in flight.  2 (the default at N = 1): two contexts take turns, step k + 1 is queued before the host "
-                         "takes step k's result -- the device never waits for the host; 1 (the default at N > 1: ONE context, ONE communicator, "
-                         "the collective behind the emit kernel on the extract's own stream -- the configuration with the fewest parts that "
-                         "have never run with a world > 1): every step ends with its host wait (also reported as step_latency_ms)")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+                    help="grid1024: steps in flight.  2 (default): two contexts take turns, step k + 1 is queued before the host takes step "
+                         "k's result -- the device never waits for the host.  At N > 1 both contexts issue their all-gather through ONE "
+                         "communicator (vtmc_comm_share), behind the emit kernel on the one stream everything runs on: for RCCL the same as a "
+                         "single context.  1: every step ends with its host wait (the latency of an isolated step, also reported as step_latency_ms)")
     ap.add_argument("--gather-beside", action="store_true",
                     help="N > 1, opt-in: the all-gather on the context's second stream beside the emit kernel (tuning key gather_beside)")
     ap.add_argument("--no-dense", action="store_true", help="A/B: force the per-block classify kernel")
@@ -288,8 +288,8 @@ def run_grid(args, torch, dist):
     n_chunks_total = (world_dims[0] // c) * (world_dims[1] // c) * (world_dims[2] // c)
     per_rank = (n_chunks_total + world - 1) // world   # slots per rank in the gathered array (zero-padded)
     bpv = (c // 8) ** 3
-    depth = args.pipeline if args.pipeline else (2 if world == 1 else 1)
-    exs = [vt.Extractor(local) for _ in range(depth)]   # depth 2: the contexts take turns, each with its own result buffers (and communicator)
+    depth = args.pipeline
+    exs = [vt.Extractor(local) for _ in range(depth)]   # depth 2: the contexts take turns, each with its own result buffers; they share ONE communicator
     ex = exs[0]
     if args.gather_beside:
         for e in exs:
@@ -308,18 +308,17 @@ def run_grid(args, torch, dist):
     sampler_s = time.perf_counter() - t0
     sampler_kernel_ms = ex.last_fill_ms()
 
-    natives = [native_comm(e, rank, world, backend, dist, torch) for e in exs]
-    native = all(natives)
-    if world > 1 and not native:
-        for e, nat in zip(exs, natives):
-            if nat:
-                e.comm_destroy()
+    # ONE communicator per rank, whatever the depth: the first context owns it, the others issue their all-gathers through it
+    # (vtmc_comm_share) -- on the one stream everything runs on, the collectives of consecutive steps are in program order on every rank
+    native = native_comm(exs[0], rank, world, backend, dist, torch)
     # rehearsal hook for a one-GPU box: the N > 1 host path (collective, pinned copy, offsets) through a world-of-one communicator
     force_comm = world == 1 and os.environ.get("VTMC_BENCH_FORCE_COMM") == "1"
     if force_comm:
-        for e in exs:
-            e.comm_init_rank(e.comm_unique_id(), 0, 1)
+        exs[0].comm_init_rank(exs[0].comm_unique_id(), 0, 1)
         native = True
+    if native:
+        for e in exs[1:]:
+            e.comm_share(exs[0])
     exchange = world > 1 or force_comm
     flags = 2 if args.no_dense else 0
     # rank r holds chunks r, r + N, ...: chunk c sits in slot c // N of rank c % N

@@ -321,6 +321,12 @@ int32_t vtmc_comm_unique_id(uint8_t id[VTMC_COMM_ID_BYTES]);
 int32_t vtmc_comm_init_rank(vtmc_ctx *ctx, const uint8_t id[VTMC_COMM_ID_BYTES], int32_t rank, int32_t world_size);
 int32_t vtmc_comm_destroy(vtmc_ctx *ctx);
 
+/* `ctx` uses the communicator of `owner` (same device, same process) for vtmc_allgather_volume_counts from now on: two contexts that take
+ * turns on ONE stream (a step in flight while the host takes the previous one) then issue all their collectives through one communicator,
+ * in stream order -- nothing for RCCL that a single context does not already do.  `ctx` never destroys the communicator; `owner` must
+ * stay alive, and keep it, as long as `ctx` uses it (vtmc_comm_destroy(ctx) or another vtmc_comm_* call on ctx ends the sharing). */
+int32_t vtmc_comm_share(vtmc_ctx *ctx, vtmc_ctx *owner);
+
 /* All-gather of volume_counts of the last extract_* on `stream` (NULL = the context's stream),
  * asynchronously: d_all_counts (device, world_size x volumes_per_rank x {vertices, triangles} u32)
  * receives rank r's pairs at [r * volumes_per_rank ...), zero-padded where a rank owns fewer volumes.

@@ -52,7 +52,7 @@ def test_strong_scaling_two_ranks_on_one_device():
     assert j["config"]["chunks_per_gpu"] == 4 and "c -> rank c % 2" in j["config"]["workload"]
     assert abs(j["triangles_total"] - 2655156) < 2000 and 0 < j["triangles_rank0"] < j["triangles_total"]
     assert j["allgather_ms"]["avg"] >= 0 and j["cpu_baseline"] is None
-    assert j["pipeline_depth"] == 1   # N > 1 default: one context, one communicator, the collective behind the emit kernel
+    assert j["pipeline_depth"] == 2   # two contexts take turns; at N > 1 they share one communicator (vtmc_comm_share)
 
 
 def test_stream_config_line():

@@ -585,9 +585,10 @@ def test_streaming_shards_cover_the_world(ex, oracle_mod):
 def test_rccl_allgather_of_counts_through_the_c_abi(ex, oracle_mod, c, n_vol, per_rank, indexed):
     """The path's one collective behind the C ABI (vtmc_comm_* + vtmc_allgather_volume_counts): a
     world of one rank round-trips its per-chunk {vertices, triangles} through RCCL, padded to
-    volumes_per_rank.  128^3 chunks are whole scan tiles, so there the counts leave the scan kernel and
-    the collective is queued on the context's second stream beside the emit kernel; 32^3 chunks take the
-    emit-prologue route on the caller's stream.  (Two ranks on one device are refused by RCCL; the
+    volumes_per_rank.  By default the collective is queued behind the emit kernel on the caller's stream; with
+    gather_beside = 1 (second round) and 128^3 chunks -- whole scan tiles, the counts leave the scan kernel -- it runs
+    on the context's second stream beside the emit kernel.  A second context borrows the communicator
+    (vtmc_comm_share: bench.py's two contexts taking turns).  (Two ranks on one device are refused by RCCL; the
     multi-rank path is the same call with world_size > 1 and is covered on CPU by
     tests/test_sharding_gloo.py's layout checks.)"""
     import torch
@@ -603,7 +604,8 @@ def test_rccl_allgather_of_counts_through_the_c_abi(ex, oracle_mod, c, n_vol, pe
             e2.allgather_volume_counts(0, 4)
         assert err.value.code == -5                       # no communicator yet
         e2.comm_init_rank(e2.comm_unique_id(), 0, 1)
-        for rep in range(2):                               # the second round reuses the streams, events and send buffer
+        for rep in range(2):                               # the second round reuses the events and send buffer, beside the emit kernel
+            e2.set_tuning(gather_beside=rep)
             gathered = torch.full((1, per_rank, 2), 0x7FFFFFFF, dtype=torch.int32, device="cuda")
             torch.cuda.synchronize()
             e2.extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), n_vol, dim ** 3)
@@ -619,6 +621,22 @@ def test_rccl_allgather_of_counts_through_the_c_abi(ex, oracle_mod, c, n_vol, pe
         with pytest.raises(vt.VtmcError) as err:
             e2.allgather_volume_counts(gathered.data_ptr(), n_vol - 1)
         assert err.value.code == -3
+        # a second context issues its all-gather through the first one's communicator and never destroys it
+        with vt.Extractor(0) as e3:
+            e3.set_output_mode(indexed)
+            with pytest.raises(vt.VtmcError) as err:
+                e3.comm_share(e3)
+            assert err.value.code == -1
+            e3.comm_share(e2)
+            gathered.fill_(0x7FFFFFFF)
+            torch.cuda.synchronize()
+            e3.extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), n_vol, dim ** 3)
+            e3.allgather_volume_counts(gathered.data_ptr(), per_rank)
+            host = e3.copy_u32(gathered.data_ptr(), 2 * per_rank).reshape(per_rank, 2)
+            assert e3.extract_finish() == sum(want) and list(host[:n_vol, 1]) == want and list(host[:n_vol, 0]) == want_v
+        e2.allgather_volume_counts(gathered.data_ptr(), per_rank)      # the borrower is gone, the communicator is not
+        host = e2.copy_u32(gathered.data_ptr(), 2 * per_rank).reshape(per_rank, 2)
+        assert list(host[:n_vol, 1]) == want
         e2.comm_destroy()
 
 

@@ -34,7 +34,7 @@ SYMBOLS = [
     "vtmc_terrain_init", "vtmc_terrain_update", "vtmc_terrain_dirty_blocks", "vtmc_terrain_read_samples",
     "vtmc_terrain_device_grid", "vtmc_copy_volume_counts_device", "vtmc_density_fill_device_async",
     "vtmc_set_output_mode", "vtmc_last_vertex_count", "vtmc_read_indexed_mesh", "vtmc_device_indexed_results",
-    "vtmc_comm_unique_id", "vtmc_comm_init_rank", "vtmc_comm_destroy", "vtmc_allgather_volume_counts",
+    "vtmc_comm_unique_id", "vtmc_comm_init_rank", "vtmc_comm_destroy", "vtmc_comm_share", "vtmc_allgather_volume_counts",
     "vtmc_copy_to_host", "vtmc_chunk_write", "vtmc_chunk_read",
     "vtmc_extract_volumes_device_async", "vtmc_extract_finish", "vtmc_last_fill_ms",
 ]
@@ -134,6 +134,7 @@ def load():
     L.vtmc_comm_unique_id.argtypes = [vp]
     L.vtmc_comm_init_rank.argtypes = [vp, vp, i32, i32]
     L.vtmc_comm_destroy.argtypes = [vp]
+    L.vtmc_comm_share.argtypes = [vp, vp]
     L.vtmc_allgather_volume_counts.argtypes = [vp, vp, i32, vp]
     L.vtmc_copy_to_host.argtypes = [vp, vp, vp, i64, vp]
     L.vtmc_chunk_write.argtypes = [vp, ctypes.c_char_p, i32, P(i32 * 3), i32]

@@ -92,7 +92,8 @@ void comm_release(vtmc_ctx *ctx)
         if (ctx->pending.active && ctx->pending.stream) (void)hipStreamSynchronize(ctx->pending.stream);   // a queued extract's collective
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         const RcclApi &a = rccl();
-        if (a.handle) (void)a.CommDestroy((ncclComm_t)ctx->comm);
+        if (a.handle && !ctx->comm_borrowed) (void)a.CommDestroy((ncclComm_t)ctx->comm);
+        ctx->comm_borrowed = false;
         ctx->comm = nullptr;
         ctx->comm_world = 1;
         ctx->comm_rank = 0;
@@ -130,6 +131,21 @@ int32_t vtmc_comm_init_rank(vtmc_ctx *ctx, const uint8_t id[VTMC_COMM_ID_BYTES],
     ctx->comm = c;
     ctx->comm_rank = rank;
     ctx->comm_world = world_size;
+    return VTMC_OK;
+}
+
+int32_t vtmc_comm_share(vtmc_ctx *ctx, vtmc_ctx *owner)
+{
+    if (!ctx || !owner) return VTMC_ERR_INVALID_ARG;
+    if (ctx == owner) return fail(ctx, VTMC_ERR_INVALID_ARG, "a context cannot borrow its own communicator");
+    if (!owner->comm || owner->comm_borrowed) return fail(ctx, VTMC_ERR_NO_RESULT, "the owner holds no communicator of its own (vtmc_comm_init_rank)");
+    if (owner->device != ctx->device) return fail(ctx, VTMC_ERR_INVALID_ARG, "the two contexts are on different devices (%d, %d)", ctx->device, owner->device);
+    VTMC_HIP(ctx, hipSetDevice(ctx->device));
+    comm_release(ctx);
+    ctx->comm = owner->comm;
+    ctx->comm_borrowed = true;
+    ctx->comm_rank = owner->comm_rank;
+    ctx->comm_world = owner->comm_world;
     return VTMC_OK;
 }
 

@@ -74,6 +74,7 @@ struct vtmc_ctx {
     // chunk_io.hip: file image being assembled / last image read
     VtmcDevBuf chunk_image;
     // comm.hip: RCCL communicator (opaque ncclComm_t) + the padded send buffer of the counts all-gather
+    bool comm_borrowed = false;   // comm belongs to another context (vtmc_comm_share): never destroyed through this one
     void *comm = nullptr;
     int comm_rank = 0, comm_world = 1;
     VtmcDevBuf comm_send;

@@ -203,6 +203,10 @@ class Extractor:
     def comm_destroy(self):
         self._check(self._L.vtmc_comm_destroy(self._h))
 
+    def comm_share(self, owner):
+        """This context issues its all-gathers through `owner`'s communicator (two contexts taking turns on one stream)."""
+        self._check(self._L.vtmc_comm_share(self._h, owner._h))
+
     def allgather_volume_counts(self, d_all_counts, volumes_per_rank, stream=None):
         """Queues the all-gather of the last extract's per-volume {vertices, triangles} on `stream`:
         d_all_counts (device, world x volumes_per_rank x 2 u32).  Asynchronous."""
