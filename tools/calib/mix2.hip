@@ -148,6 +148,47 @@ static void run_chunks(const char *name, int wgs_per_cu, int n_cus, v4f *dst, lo
     fflush(stdout);
 }
 
+
+// Read-only stream in the classify kernel's load shape: ONE dword per lane and instruction (a wave-instruction moves 256 bytes), U loads
+// in flight per lane, rows `pitch` floats apart (130: a chunk's row pitch; 64: dense).  Is 4 bytes per lane the classify kernel's limit?
+template <int U>
+__global__ __launch_bounds__(256) void read_dword_kernel(const float *__restrict__ src, long long n_rows, int pitch, float *__restrict__ sink)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * 256) >> 6;
+    float acc = 0.f;
+    for (long long r0 = wave * U; r0 < n_rows; r0 += n_waves * U) {
+        float v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) v[j] = r0 + j < n_rows ? src[(r0 + j) * pitch + lane] : 0.f;
+#pragma unroll
+        for (int j = 0; j < U; ++j) acc += v[j];
+    }
+    if (acc == 1.2345e30f) sink[0] = acc;
+}
+
+template <int U>
+static void run_dword(int wgs_per_cu, int n_cus, const float *src, long long n_floats, int pitch, float *sink, int reps)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const long long n_rows = n_floats / pitch - 1;
+    std::vector<float> ms(reps);
+    for (int i = 0; i < reps + 1; ++i) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((read_dword_kernel<U>), dim3(wgs_per_cu * n_cus), dim3(256), 0, 0, src, n_rows, pitch, sink);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        if (i) CK(hipEventElapsedTime(&ms[i - 1], e0, e1));
+    }
+    std::sort(ms.begin(), ms.end());
+    const double bytes = (double)n_rows * 256.0, touched = (double)n_rows * pitch * 4.0;
+    printf("{\"kernel\": \"read_dword\", \"in_flight\": %d, \"wgs_per_cu\": %d, \"pitch_floats\": %d, \"GB_loaded\": %.3f, \"ms_med\": %.4f, \"TBps_loaded\": %.3f, "
+           "\"TBps_of_lines_touched\": %.3f}\n", U, wgs_per_cu, pitch, bytes / 1e9, ms[reps / 2], bytes / ms[reps / 2] / 1e9, touched / ms[reps / 2] / 1e9);
+    fflush(stdout);
+}
+
 template <int R, int W, int U, bool NT>
 static void run(const char *name, int wgs_per_cu, int n_cus, const v4f *src, v4f *dst, long long n_units, int reps)
 {
@@ -184,6 +225,22 @@ int main(int argc, char **argv)
     CK(hipMalloc(&buf, total_f4 * 16));
     CK(hipMemset(buf, 0, total_f4 * 16));
     const int reps = 7;
+
+    if (argc > 2 && !strcmp(argv[2], "dword")) {
+        const float *src = reinterpret_cast<const float *>(buf);
+        float *sink = reinterpret_cast<float *>(buf);
+        const long long n_floats = total_f4 * 4;
+        for (int pitch : {64, 65, 130}) {
+            for (int per_cu : {8, 4, 3, 2}) {
+                run_dword<1>(per_cu, n_cus, src, n_floats, pitch, sink, reps);
+                run_dword<9>(per_cu, n_cus, src, n_floats, pitch, sink, reps);
+                run_dword<27>(per_cu, n_cus, src, n_floats, pitch, sink, reps);
+                run_dword<81>(per_cu, n_cus, src, n_floats, pitch, sink, reps);
+            }
+        }
+        CK(hipFree(buf));
+        return 0;
+    }
 
     if (argc > 2 && !strcmp(argv[2], "chunks")) {
         const long long f4 = (3ll << 30) / 16;   // 3 GiB written per launch (the emit kernel writes 3.23 GB)
