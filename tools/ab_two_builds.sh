@@ -1,5 +1,6 @@
 #!/bin/bash
-# same-box A/B of two library builds: the tree's (new) against tools/_ab/libvtmc_prev.so, alternating processes
+# Same-box A/B of two library BUILDS (kernel changes that are no tuning key): the tree's library against tools/_ab/libvtmc_prev.so
+# (build the older commit, copy its libvtmc.so there), alternating processes on one box.  usage: gpurun -- 'bash tools/ab_two_builds.sh'
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 for i in 1 2; do

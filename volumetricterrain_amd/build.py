@@ -24,15 +24,18 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared"
          "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
 
 
+# the device code of the extract path and the tuning defaults that select its variants (host-side files do not change a kernel's traffic)
+EXTRACT_KERNEL_FILES = ["classify_kernels.hip", "emit_kernels.hip", "emit_device.h", "mc_device.h", "mc_tables_packed.h", "vtmc_internal.h"]
+
+
 def kernel_source_hash():
-    """SHA-256 over the kernel sources (csrc/*.hip, csrc/*.h): profiles/pmc_traffic.json records it next to the counter values it was
+    """SHA-256 over the extract path's kernel sources: profiles/pmc_traffic.json records it next to the counter values it was
     measured with, and bench.py reports `traffic` only while the sources still hash to the same value."""
     import hashlib
     h = hashlib.sha256()
-    for name in sorted(os.listdir(CSRC)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(CSRC, name), "rb").read())
+    for name in EXTRACT_KERNEL_FILES:
+        h.update(name.encode())
+        h.update(open(os.path.join(CSRC, name), "rb").read())
     return h.hexdigest()
 
 
