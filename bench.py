@@ -336,13 +336,21 @@ def run_grid(args, torch, dist):
             self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self.copied = torch.cuda.Event()
             self.timed_gather = False
+            self.timed_stages = True
 
     slots = [Slot(e) for e in exs]
     stage_acc = {"classify": 0.0, "scan": 0.0, "emit": 0.0, "total": 0.0}
+    stage_steps = [0]   # steps whose three kernels were timed one by one
+    # N > 1: a rank's kernels take 0.14 ms each, and the HIP events between them cost 2 % of its step (tools/rank_step.py): only every eighth
+    # step carries them (the same steps whose collective is timed); at N = 1 every step does (0.3 % of a step)
+    sample_stages = world > 1
     gather_ms = []
 
-    def queue(sl, timed_gather=False):
+    def queue(sl, timed_gather=False, timed_stages=True):
         """classify -> scan -> emit [-> all-gather -> copy of the gathered pairs into pinned words]; nothing waits."""
+        if sample_stages:
+            sl.ex.set_tuning(stage_events=1 if timed_stages else 0)
+        sl.timed_stages = timed_stages
         sl.ex.extract_volumes_device_async(d_ptr, (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, s_ptr, flags)
         if exchange:
             sl.timed_gather = timed_gather
@@ -372,10 +380,11 @@ def run_grid(args, torch, dist):
         if exchange:   # every rank's local exclusive scan over the chunks in global order
             np.cumsum(sl.host_rows[perm], axis=0, dtype=np.int64, out=sl.offs[1:])
             offs = sl.offs
-        if accumulate:
+        if accumulate and sl.timed_stages:
             ms = sl.ex.last_stage_ms()
             for k in stage_acc:
                 stage_acc[k] += ms[k]
+            stage_steps[0] += 1
             if exchange and sl.timed_gather:
                 gather_ms.append(sl.ev0.elapsed_time(sl.ev1))
         return T, offs
@@ -384,7 +393,8 @@ def run_grid(args, torch, dist):
         """k_steps steps, `depth` in flight: step i + 1 is queued before the host takes step i."""
         T = offs = None
         for i in range(k_steps):
-            queue(slots[i % depth], timed_gather=accumulate and exchange and i % 8 == 0)   # the collective's own events on every eighth step
+            queue(slots[i % depth], timed_gather=accumulate and exchange and i % 8 == 0,   # the collective's own events on every eighth step
+                  timed_stages=(not sample_stages) or i % 8 == 0)
             if i >= depth - 1:
                 T, offs = complete(slots[(i - depth + 1) % depth], accumulate)
         for i in range(max(k_steps - depth + 1, 0), k_steps):
@@ -421,7 +431,7 @@ def run_grid(args, torch, dist):
 
     if rank == 0:
         # -- roofline of the dominant kernel (rank 0's launches, HIP events inside libvtmc) --------
-        avg = {k: v / args.steps for k, v in stage_acc.items()}
+        avg = {k: v / max(stage_steps[0], 1) for k, v in stage_acc.items()}
         samples = n_chunks * dim ** 3
         _, off_ptr, _ = ex.device_results()
         boffs = ex.copy_u32(off_ptr, n_chunks * bpv + 1).astype(np.int64)

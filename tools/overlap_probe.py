@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--n", type=int, default=1024)
     ap.add_argument("--indexed", type=int, default=0)
+    ap.add_argument("--limit", type=int, default=0, help="use only the first K chunks (64: the share of one rank of eight)")
     args = ap.parse_args()
     import torch
     import volumetricterrain_amd as vt
@@ -27,6 +28,8 @@ def main():
     n, c = args.n, 128
     dim = c + 2
     origins = sharding.chunk_origins(n, c)
+    if args.limit:
+        origins = origins[:args.limit]
     exs = [vt.Extractor(0) for _ in range(2)]
     d = torch.empty(len(origins) * dim ** 3, dtype=torch.float32, device="cuda")
     exs[0].density_fill_device(vt.density_params("perlin3d", n), origins, (dim, dim, dim), (1, dim, dim * dim), dim ** 3, d.data_ptr())
