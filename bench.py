@@ -74,6 +74,10 @@ def parse():
                          "k's result -- the device never waits for the host.  At N > 1 both contexts issue their all-gather through ONE "
                          "communicator (vtmc_comm_share), behind the emit kernel on the one stream everything runs on: for RCCL the same as a "
                          "single context.  1: every step ends with its host wait (the latency of an isolated step, also reported as step_latency_ms)")
+    ap.add_argument("--gather-stream", default="side", choices=["side", "main"],
+                    help="N > 1: the stream the all-gather and the copy of its result are queued on.  side (default): a second stream, ordered "
+                         "behind the extract's emit launch by an event -- the main stream never waits for the collective, it overlaps the next "
+                         "step's classify kernel; main: behind the emit kernel on the extract's own stream")
     ap.add_argument("--gather-beside", action="store_true",
                     help="N > 1, opt-in: the all-gather on the context's second stream beside the emit kernel (tuning key gather_beside)")
     ap.add_argument("--no-dense", action="store_true", help="A/B: force the per-block classify kernel")
@@ -339,6 +343,7 @@ def run_grid(args, torch, dist):
             self.timed_stages = True
 
     slots = [Slot(e) for e in exs]
+    side = torch.cuda.Stream() if (exchange and native and args.gather_stream == "side" and not args.gather_beside) else None
     stage_acc = {"classify": 0.0, "scan": 0.0, "emit": 0.0, "total": 0.0}
     stage_steps = [0]   # steps whose three kernels were timed one by one
     # N > 1: a rank's kernels take 0.14 ms each, and the HIP events between them cost 2 % of its step (tools/rank_step.py): only every eighth
@@ -356,7 +361,18 @@ def run_grid(args, torch, dist):
             sl.timed_gather = timed_gather
             if timed_gather:
                 sl.ev0.record(stream)
-            if native:     # the path's one collective, behind the C ABI; beside the emit kernel when the chunks are whole scan tiles
+            if native and side is not None:
+                # the path's one collective, behind the C ABI, on a stream of its own: the library orders it behind this extract's emit
+                # launch (an event), the copy of the gathered pairs follows it there, and the main stream goes straight on to the next
+                # step's classify kernel -- nothing on it waits for the collective, only the host does (`copied`)
+                sl.ex.allgather_volume_counts(sl.gathered.data_ptr(), per_rank, side.cuda_stream)
+                if timed_gather:
+                    sl.ev1.record(side)
+                with torch.cuda.stream(side):
+                    sl.gathered_host.copy_(sl.gathered, non_blocking=True)
+                sl.copied.record(side)
+                return
+            if native:     # --gather-stream main: behind the emit kernel on the extract's own stream (or beside it with --gather-beside)
                 sl.ex.allgather_volume_counts(sl.gathered.data_ptr(), per_rank, s_ptr)
             else:
                 sl.ex.copy_volume_counts_device(sl.counts_dev.data_ptr(), per_rank, s_ptr)
@@ -514,7 +530,7 @@ def run_grid(args, torch, dist):
             "data": "synthetic",
             "config": {"workload": wl, "grid": n, "chunk": c, "chunks_per_gpu": n_chunks, "kind": args.kind, "seed": 1337,
                        "pipeline": "classify(per-block) -> scan -> emit" if args.no_dense else "classify(dense) -> scan -> emit",
-                       "collective": None if world == 1 else ("rccl all-gather via libvtmc (vtmc_allgather_volume_counts)" if native
+                       "collective": None if world == 1 else (("rccl all-gather via libvtmc (vtmc_allgather_volume_counts), %s" % ("on a second stream behind the emit launch's event" if side is not None else "on the extract's stream")) if native
                                                               else "torch.distributed all_gather (%s)" % backend)},
             "mtris_per_s": round(total_tris / (elapsed / args.steps) / 1e6, 1),
             "triangles_rank0": int(T),
@@ -524,7 +540,7 @@ def run_grid(args, torch, dist):
             "kernels": per_kernel,
             "path_roofline": path,
             "allgather_ms": None if not gather_ms else {"avg": round(statistics.mean(gather_ms), 4), "max": round(max(gather_ms), 4),
-                                                     "note": "rank 0, HIP events on the extract's stream from the end of the emit launch to the end of the collective: what the collective adds to the step (behind the emit kernel on that stream by default; beside it with --gather-beside); sampled on every eighth step"},
+                                                     "note": "rank 0, HIP events from the end of the emit kernel to the end of the collective (sampled on every eighth step).  With --gather-stream side (default) the collective runs on a second stream and overlaps the next step's classify kernel: this is its own duration, not a cost of the step"},
             "host_ms_per_step_beyond_kernels": round(ms_per_step - avg["total"], 4),
             "pipeline_depth": depth,
             "step_latency_ms": round(step_latency_ms, 4),

@@ -634,6 +634,17 @@ def test_rccl_allgather_of_counts_through_the_c_abi(ex, oracle_mod, c, n_vol, pe
             e3.allgather_volume_counts(gathered.data_ptr(), per_rank)
             host = e3.copy_u32(gathered.data_ptr(), 2 * per_rank).reshape(per_rank, 2)
             assert e3.extract_finish() == sum(want) and list(host[:n_vol, 1]) == want and list(host[:n_vol, 0]) == want_v
+        # the collective on a stream of the caller's that is NOT the extract's: the library orders it behind the extract's emit launch
+        # (bench.py's default at N > 1: the main stream never waits for the collective)
+        side = torch.cuda.Stream()
+        gathered.fill_(0x7FFFFFFF)
+        torch.cuda.synchronize()
+        e2.set_tuning(gather_beside=0)
+        e2.extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), n_vol, dim ** 3)
+        e2.allgather_volume_counts(gathered.data_ptr(), per_rank, side.cuda_stream)
+        side.synchronize()
+        host = gathered.cpu().numpy().reshape(per_rank, 2)
+        assert e2.extract_finish() == sum(want) and list(host[:n_vol, 1]) == want and list(host[:n_vol, 0]) == want_v
         e2.allgather_volume_counts(gathered.data_ptr(), per_rank)      # the borrower is gone, the communicator is not
         host = e2.copy_u32(gathered.data_ptr(), 2 * per_rank).reshape(per_rank, 2)
         assert list(host[:n_vol, 1]) == want

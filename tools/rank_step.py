@@ -2,12 +2,14 @@
 """Strong-scaling rehearsal on ONE GPU: times the step of rank r of a W-rank run of BASELINE configs[3]
 (its 512 / W chunks of the 1024^3 world: queued extract + the one host wait, no collective) next to the
 whole 512-chunk step, i.e. the speed-up the sharding leaves before the all-gather's ~tens of microseconds.
-    python tools/rank_step.py [--comm | --comm-beside] [--pipeline] [W ...]
+    python tools/rank_step.py [--comm | --comm-beside | --comm-side] [--pipeline] [W ...]
 --pipeline: two contexts take turns, step k + 1 is queued before the host takes step k (what bench.py does by default; with --comm the
 second context borrows the first one's communicator, vtmc_comm_share) -- the throughput per step instead of an isolated step's latency.
 --comm: every step also queues the C ABI's all-gather (a world-of-one RCCL communicator: its stream ordering, events and
 the copy of the gathered array are real, the wire is not) -- the fixed cost of the exchange, behind the emit kernel on the
-extract's stream (the library's default); --comm-beside: on the context's second stream beside the emit kernel (opt-in)."""
+extract's stream (the library's default); --comm-beside: on the context's second stream beside the emit kernel (opt-in);
+--comm-side: on a second stream of the CALLER's, which the library orders behind the extract's emit launch -- bench.py's default at N > 1:
+the main stream never waits for the collective."""
 import os
 import sys
 import time
@@ -26,6 +28,7 @@ out = {}
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 with_comm = any(a.startswith("--comm") for a in sys.argv[1:])
 pipelined = "--pipeline" in sys.argv[1:]
+side = torch.cuda.Stream() if "--comm-side" in sys.argv[1:] else None
 no_stage_events = "--no-stage-events" in sys.argv[1:]   # only the step's total is timed on the device: no events between the three kernels
 ex2 = vt.Extractor(0) if pipelined else None
 if no_stage_events:
@@ -65,7 +68,12 @@ for W in [1] + [int(a) for a in args or ["2", "4", "8"]]:
             def queue(i):
                 e, g, gh, ev = slots[i % 2]
                 e.extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), len(org), dim ** 3, stream.cuda_stream, 0)
-                if with_comm:
+                if with_comm and side is not None:
+                    e.allgather_volume_counts(g.data_ptr(), len(org), side.cuda_stream)
+                    with torch.cuda.stream(side):
+                        gh.copy_(g, non_blocking=True)
+                    ev.record(side)
+                elif with_comm:
                     e.allgather_volume_counts(g.data_ptr(), len(org), stream.cuda_stream)
                     gh.copy_(g, non_blocking=True)
                     ev.record(stream)
