@@ -9,7 +9,7 @@ compiles emit_kernels.hip to gfx950 assembly and checks, for every kernel with a
   * the destination registers of the asm loads / atomics are touched by nothing but inline asm, the ds_write of the tile into LDS,
     v_readfirstlane of the ticket and (before the first asm statement) their initialisation;
   * the kernel has no scratch and no VGPR spills;
-  * inside the main loop the compiler itself emits no `s_waitcnt vmcnt` for the dense path (only the block-list path may).
+  * inside the main loop the compiler itself emits no `s_waitcnt vmcnt` at all (the dirty list is read by scalar loads).
 
 usage: tools/isa_audit.py [--keep file.s]      exit code 0 = clean
 """
@@ -89,7 +89,34 @@ def audit_kernel(name, lines):
         if touched:
             problems.append("%s: line %d touches v%s while its asm load is in flight: %s" % (name[:60], i, sorted(touched), code))
     problems += sgpr_hazards(name, lines)
+    if n_loads:
+        problems += compiler_waits_in_loop(name, lines)
     return (n_loads or None), problems
+
+
+def compiler_waits_in_loop(name, lines):
+    """From the counted wait at the head of the main loop (the last wait ladder in the text) to the wave's final wait, hipcc itself must
+    not emit a single `s_waitcnt vmcnt`: one such wait in the loop drains the stores the asynchronous prefetch exists to leave in flight."""
+    ladders, in_asm, start = [], False, 0
+    for i, l in enumerate(lines):
+        if "#ASMSTART" in l:
+            in_asm, start = True, i
+        elif "#ASMEND" in l:
+            in_asm = False
+        elif in_asm and "s_waitcnt vmcnt(48)" in l:
+            ladders.append(start)
+    if not ladders:
+        return ["%s: no counted wait found" % name[:60]]
+    problems, in_asm = [], False
+    for i in range(ladders[-1], len(lines)):
+        l = lines[i]
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        elif not in_asm and "s_waitcnt" in l and "vmcnt" in l:
+            problems.append("%s: line %d: the compiler waits on vmcnt inside the main loop: %s" % (name[:60], i, l.strip()))
+    return problems
 
 
 def sgpr_hazards(name, lines):

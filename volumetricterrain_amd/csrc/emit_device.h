@@ -465,6 +465,7 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
         const unsigned n = (unsigned)(vw >> 60);
         unsigned step_total;
         const unsigned pre_n = wave_prefix3(n, step_total);
+        if (pending + (int)step_total > kSlotCap) break;   // wave-uniform; cannot happen while the scan's count (budget <= kSlotCap) describes this tile: never outside the slot buffer
         unsigned *dst = L->c.slot + pending + pre_n;
 #pragma unroll
         for (unsigned i = 0; i < 5; ++i)

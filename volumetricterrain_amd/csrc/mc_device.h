@@ -43,7 +43,10 @@ __device__ __forceinline__ unsigned wave_prefix3(unsigned n, unsigned &total)
 __device__ __forceinline__ long long block_origin(const BlockSpace &s, int b)
 {
     if (s.list) {
-        const int *p = s.list + 3ll * b;
+        // the dirty list is written before the launch and never during it: read through the constant address space, i.e. by scalar loads
+        // (b is wave-uniform) -- a vector load here would put a `vmcnt(0)` of the compiler's into the emit kernels' asynchronous loop
+        typedef const __attribute__((address_space(4))) int *const_int_ptr;
+        const_int_ptr p = (const_int_ptr)(s.list + 3ll * b);
         return 8ll * (p[0] * s.sx + p[1] * s.sy + p[2] * s.sz);
     }
     const int v = (int)s.d_bpv.quot((unsigned)b);
