@@ -477,18 +477,29 @@ def run_grid(args, torch, dist):
         # per triangle: a few steps after the timed region, N = 1 only (not part of `value`)
         indexed = None
         if world == 1 and not args.no_indexed:
-            ex.set_output_mode(True)
+            for e in exs:
+                e.set_output_mode(True)
             try:
-                for _ in range(2):
-                    ex.extract_volumes_device(d_field.data_ptr(), (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, stream.cuda_stream, flags)
+                # driven exactly as the timed soup steps: `depth` steps in flight, the contexts taking turns
+                def run_indexed(k_steps, acc):
+                    Ti = None
+                    for i in range(k_steps + depth - 1):
+                        if i < k_steps:
+                            exs[i % depth].extract_volumes_device_async(d_ptr, (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, s_ptr, flags)
+                        if i >= depth - 1:
+                            e = exs[(i - depth + 1) % depth]
+                            Ti = e.extract_finish()
+                            if acc is not None:
+                                for k, v in e.last_stage_ms().items():
+                                    acc[k] += v / k_steps
+                    return Ti
+
+                run_indexed(2 * depth, None)
                 acc = {"classify": 0.0, "scan": 0.0, "emit": 0.0, "total": 0.0}
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                K = max(3, args.steps // 2)
-                for _ in range(K):
-                    Ti = ex.extract_volumes_device(d_field.data_ptr(), (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, stream.cuda_stream, flags)
-                    for k, v in ex.last_stage_ms().items():
-                        acc[k] += v / K
+                K = max(4, args.steps // 2)
+                Ti = run_indexed(K, acc)
                 torch.cuda.synchronize()
                 ms_i = (time.perf_counter() - t0) / K * 1e3
                 V = ex.last_vertex_count()
@@ -502,7 +513,8 @@ def run_grid(args, torch, dist):
                                              "read_only_frac_of_peak": round(4.0 * samples / (acc["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                            "speedup_over_soup_step": round(ms_per_step / ms_i, 3)}
             finally:
-                ex.set_output_mode(False)
+                for e in exs:
+                    e.set_output_mode(False)
         cpu = None
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             k = min(args.cpu_sample_chunks, n_chunks)
