@@ -298,6 +298,10 @@ def run_grid(args, torch, dist):
     if args.gather_beside:
         for e in exs:
             e.set_tuning(gather_beside=1)
+    if os.environ.get("VTMC_BENCH_TUNING"):   # A/B of kernel variants under the bench's sustained load, e.g. VTMC_BENCH_TUNING="emit_once=0"
+        kv = {k: int(v) for k, v in (item.split("=") for item in os.environ["VTMC_BENCH_TUNING"].split(","))}
+        for e in exs:
+            e.set_tuning(**kv)
     # one explicit (non-default) HIP stream for everything: the library's kernels, the all-gather and the
     # copy of the gathered counts are ordered by it
     stream = torch.cuda.Stream()
