@@ -72,6 +72,20 @@ namespace {
 // One launch of the emit stage on the pending extract's stream, followed by the asynchronous copy of
 // the scan's totals into pinned memory.  The kernel itself refuses to run past its buffers' capacity
 // (it compares the device-resident T / V with the capacities it is handed).
+// The one-launch form of the step (onepass_kernels.hip) on the pending extract's stream.
+int queue_onepass(vtmc_ctx *ctx)
+{
+    const VtmcPending &pe = ctx->pending;
+    const size_t tcap = std::min<size_t>(ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
+    ctx->pending.tcap = tcap;
+    ctx->pending.vcap = 0;
+    uint32_t *vc = pe.n_volumes > 0 ? (uint32_t *)ctx->volcounts.p : nullptr;
+    VTMC_HIP(ctx, launch_onepass(pe.sp, ctx->tables, ctx->partials.p, (uint32_t *)ctx->offsets.p, ctx->tris.p, (uint32_t)tcap, (uint32_t *)ctx->totals.p,
+                                 ctx->h_totals_dev, vc, pe.n_volumes, ctx->n_cus, ctx->tune, pe.stream));
+    VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], pe.stream));
+    return VTMC_OK;
+}
+
 int queue_emit(vtmc_ctx *ctx, bool retry)
 {
     const VtmcPending &pe = ctx->pending;
@@ -159,6 +173,22 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
                        ((sp.sx == 1 && sp.nx >= 32) || (sp.sx != 1 && sp.sz == 1 && sp.nbz * 8 >= 32));
 
     ctx->h_totals[8] = 0u;   // the scan's look-back time-out word
+    if (dense && ctx->tune.one_pass && !indexed && sp.sx == 1 && !(ctx->tune.fill_keeps_signs && ctx->sign_of.valid)) {
+        // one launch: every wave classifies a brick, takes its place in the output from a chained scan and emits it (onepass_kernels.hip)
+        if (int rc = ensure(ctx, ctx->partials, std::max(onepass_ctrl_bytes(sp), sizeof(unsigned long long) * 2 * ctrl_words))) return rc;
+        VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
+        if (ctx->tune.stage_events) {
+            VTMC_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
+            VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
+        }
+        pe.one_pass = true;
+        pe.active = true;
+        pe.launched = true;
+        ctx->pending = pe;
+        const int rc = queue_onepass(ctx);
+        if (rc) ctx->pending = VtmcPending{};
+        return rc;
+    }
     unsigned long long *ctrl = (unsigned long long *)ctx->partials.p;
     const int n_ctrl = (int)(ctrl_words * (indexed ? 2 : 1));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
@@ -236,6 +266,10 @@ int extract_finish(vtmc_ctx *ctx, int64_t *tri_count)
             }
             if ((size_t)V > ctx->pending.vcap)
                 if (int rc = ensure(ctx, ctx->verts, sizeof(vtmc_vertex) * ((size_t)V + (size_t)V / 8 + 1024))) return rc;
+            if (pe.one_pass) {
+                if (int rc = queue_onepass(ctx)) return rc;
+                continue;
+            }
             VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], pe.stream));
             if (int rc = queue_emit(ctx, true)) return rc;
         }
@@ -718,6 +752,10 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     else if (k == "emit_dynamic") ctx->tune.emit_dynamic = value;
     else if (k == "emit_async") ctx->tune.emit_async = value;
     else if (k == "emit_once") ctx->tune.emit_once = value;
+    else if (k == "one_pass") ctx->tune.one_pass = value;
+    else if (k == "one_pass_unit") ctx->tune.one_pass_unit = value;
+    else if (k == "one_pass_depth") ctx->tune.one_pass_depth = value;
+    else if (k == "one_pass_prefetch") ctx->tune.one_pass_prefetch = value;
     else if (k == "emit_ablate") ctx->tune.emit_ablate = value;
     else if (k == "classify_ablate") ctx->tune.classify_ablate = value;
     else if (k == "emit_row_masks") ctx->tune.emit_row_masks = value;

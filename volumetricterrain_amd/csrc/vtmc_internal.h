@@ -76,6 +76,10 @@ struct Tuning {
     int emit_async = 1;       // 1: tile prefetch and tickets outside the compiler's vmcnt bookkeeping, a block's stores are never waited for (emit_kernels.hip); 0: round 2's loop
     int emit_once = 1;        // 1 (soup, fast math): every welded vertex of a block is evaluated once into LDS, records expanded from there; 0: per triangle corner
     int emit_spare_wgs = 0;   // workgroups the emit launch leaves free (one per XCD: room for the collective's kernel beside it)
+    int one_pass = 0;         // 1 (soup, dense x-fastest batches): classify + scan + emit in ONE launch (onepass_kernels.hip); 0: three launches
+    int one_pass_depth = 0;   // one-pass: bricks a wave classifies before it emits the oldest of them (1-3; 0: 2)
+    int one_pass_prefetch = 0;   // one-pass: 1 = the next ticket is requested beside the last block of the brick being emitted (measured: +20 %, the held brick stalls the bricks behind it)
+    int one_pass_unit = 0;    // one-pass: look-back groups (64 bricks) per work unit of an XCD's ticket counter (0: a volume of the batch, or 8)
 };
 
 // scan scratch layout
@@ -112,6 +116,21 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
                                uint32_t tri_capacity,
                                uint32_t vert_capacity, void *vertices, void *indices, int n_cus, const Tuning &tune, unsigned *queue,
                                uint32_t *volume_counts, int n_volumes, hipStream_t stream);
+
+// onepass_kernels.hip: the whole step of a dense x-fastest soup batch in one launch.  `ctrl`: onepass_ctrl_bytes(sp) bytes of scratch (zeroed
+// by the launch); totals / host_totals as launch_scan_fused leaves them ({T saturating, 0, T lo, T hi}, [8] = 1 on a look-back time-out);
+// triangles of a block that would pass `capacity` are not written (the host grows the buffer and runs the step again).
+struct OnePassCtrl {
+    unsigned *queue;            // 8 ticket counters, 256 bytes apart
+    unsigned *err;              // look-back time-out
+    unsigned long long *gsum;   // per group of 64 bricks: published bricks << 40 | their triangles
+    unsigned long long *gstat;  // per group: state << 62 (1 aggregate, 2 inclusive prefix) | triangles
+    unsigned *bstat;            // per brick: 1 << 31 | triangles
+};
+size_t onepass_ctrl_bytes(const BlockSpace &sp);
+hipError_t launch_onepass(const BlockSpace &sp, const DeviceTables &tb, void *ctrl, uint32_t *offsets, void *triangles, uint32_t capacity,
+                          uint32_t *totals, uint32_t *host_totals, uint32_t *volume_counts, int n_volumes, int n_cus, const Tuning &tune,
+                          hipStream_t stream);
 
 // terrain.hip: device-resident density grid with the reference's CSG write semantics.
 struct TerrainShape {
