@@ -169,7 +169,8 @@ int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4]);
  * compiler's vmcnt bookkeeping; 0: round 2's loop), "emit_once" (default 1: with emit_fast_math, every welded vertex of a block is
  * evaluated once and the 76-byte records are expanded from LDS; 0: per triangle corner), "one_pass" (default 0; 1: a dense x-fastest
  * soup batch is classified, scanned and emitted in ONE launch -- same bytes, measured slower: DESIGN.md section 4; "one_pass_unit":
- * its look-back groups per work unit).  "emit_ablate" / "classify_ablate" switch parts
+ * its look-back groups per work unit), "emit_idx_waves" (indexed output: 4, default: four emit workgroups of four waves per CU; 3: six of
+ * three = 18 waves, measured no faster).  "emit_ablate" / "classify_ablate" switch parts
  * of a kernel off for diagnosis and make the output INVALID.  Defaults are the shipped configuration.
  * "fill_keeps_signs" (default 0) is a contract, not a variant: with 1, vtmc_density_fill_device[_async] also leaves
  * one sign bit per sample in context memory, and an extract by the SAME context of exactly that buffer (pointer,

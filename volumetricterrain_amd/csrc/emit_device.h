@@ -371,14 +371,27 @@ __device__ __forceinline__ unsigned once_edge_entry(unsigned e)
     return lx | (ly << 4) | (lz << 8) | (axis << 12) | ((axis * 729u + lx + 9u * ly + 81u * lz) << 16);
 }
 
+__device__ __forceinline__ unsigned short once_ownx_entry(unsigned b7)
+{
+    const unsigned X = b7 & 1, Y = (b7 >> 1) & 1, Z = (b7 >> 2) & 1;
+    return (unsigned short)((X * 0x202u) | (Y * 0x804u) | (Z * 0x090u) | ((X & Y) * 0x400u) | ((X & Z) * 0x020u) | ((Y & Z) * 0x040u));
+}
 __device__ __forceinline__ void once_tables_init(OnceTables *t, int tid)   // 256 threads
 {
     t->emask[tid] = (unsigned short)case_edge_mask((unsigned)tid);
     if (tid < 12) t->edge[tid] = once_edge_entry((unsigned)tid);
-    if (tid < 8) {
-        const unsigned X = tid & 1, Y = (tid >> 1) & 1, Z = (tid >> 2) & 1;
-        t->ownx[tid] = (unsigned short)((X * 0x202u) | (Y * 0x804u) | (Z * 0x090u) | ((X & Y) * 0x400u) | ((X & Z) * 0x020u) | ((Y & Z) * 0x040u));
-    }
+    if (tid < 8) t->ownx[tid] = once_ownx_entry((unsigned)tid);
+}
+// the indexed output keeps only the two small tables (its per-wave LDS decides how many waves fit a CU: the 512-byte case -> edge-mask table
+// is three nibble operations per active cell instead)
+struct IdxTables {
+    unsigned edge[12];
+    unsigned short ownx[8];
+};
+__device__ __forceinline__ void idx_tables_init(IdxTables *t, int tid)   // >= 12 threads
+{
+    if (tid < 12) t->edge[tid] = once_edge_entry((unsigned)tid);
+    if (tid < 8) t->ownx[tid] = once_ownx_entry((unsigned)tid);
 }
 
 // One mesh vertex from its descriptor (low lattice point x | y << 4 | z << 8, axis << 12): position along the edge
@@ -551,18 +564,19 @@ constexpr u64 kOwnerEdge = 0x0ull | (2ull << 4) | (4ull << 8) | (6ull << 12) |  
                            (8ull << 32) | (9ull << 36) | (11ull << 40) | (10ull << 44);   // z: (ox, oy)
 
 struct __attribute__((aligned(16))) EmitLdsIdx {
-    float tile[1000];
     union {
-        unsigned slot[kSlotCap];          // pass 2: triangle slot -> cell | edge triple << 9
-        unsigned short vlist[kVlistCap];  // vertex phase: vertex id - window -> low lattice point (x | y << 4 | z << 8) | axis << 12
-    } q;
+        float tile[1000];
+        unsigned slot[kSlotCap];          // pass 2: triangle slot -> cell | edge triple << 9.  Over the tile: nothing reads a sample after the vertex
+                                          // phase (pass 2 takes the cases from `cases`), and the next tile is stored at the top of the next block
+    } t;
+    unsigned short vlist[kVlistCap];  // vertex phase: vertex id - window -> low lattice point (x | y << 4 | z << 8) | axis << 12
     unsigned short acell[512];      // active cells of the block, ascending cell id
     union {
         unsigned char vtab[2192];   // <= 255 vertices: lattice edge (axis * 729 + x + 9 y + 81 z) -> vertex id
         unsigned cellmap[512];      // more: owner cell -> first vertex id | owned-edge mask << 16 (active cells only)
     } m;
     unsigned char cases[512];       // case of every active cell (numbering -> pass 2)
-};   // 9264 bytes: with the shared tables a workgroup takes 39.6 KB -- four per CU
+};   // 8240 bytes: with the shared tables a workgroup of THREE waves takes 27 024 bytes -- six per CU, 18 waves (four-wave workgroups: 16)
 static_assert(sizeof(EmitLdsIdx) % 16 == 0, "keeps the waves' blocks 16-byte aligned");
 
 
@@ -599,14 +613,14 @@ __device__ __forceinline__ unsigned wave_prefix4(unsigned n, unsigned &total)
 //   V : one lane per vertex (eval_vertex), two 12-byte stores per lane straight from registers.
 //   T : one lane per triangle, one 12-byte store per lane: 64 lanes write 768 contiguous bytes, no staging.
 template <bool FAST>
-__device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_vert, const unsigned short *s_own, const OnceTables *tb,
+__device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_vert, const unsigned short *s_own, const IdxTables *tb,
                                                    size_t tri_base, int tri_budget, size_t vert_base, int vert_budget,
                                                    float *__restrict__ out_vertices, int *__restrict__ out_indices, int lane, int ablate,
                                                    unsigned rowmask, int &vm_issued)
 {
     typedef float v3u __attribute__((ext_vector_type(3), aligned(4)));
     typedef int i3u __attribute__((ext_vector_type(3), aligned(4)));
-    const float *tile = L->tile;
+    const float *tile = L->t.tile;
     // pass 1: compaction of the active cells (as the soup path, row masks included)
     const int n_act = compact_active_cells(tile, L->acell, lane, rowmask);
     VTMC_WAVE_SYNC();
@@ -623,7 +637,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
             if (first && valid) L->cases[cell] = (unsigned char)cs;   // for pass 2
             const unsigned cx = cell & 7u, cy = (cell >> 3) & 7u, cz = cell >> 6;
             const unsigned b7 = (unsigned)(cx == 7u) | ((unsigned)(cy == 7u) << 1) | ((unsigned)(cz == 7u) << 2);
-            const unsigned owned = valid ? (tb->emask[cs] & (0x109u | tb->ownx[b7])) : 0u;
+            const unsigned owned = valid ? (case_edge_mask(cs) & (0x109u | tb->ownx[b7])) : 0u;
             const unsigned desc = cx | (cy << 4) | (cz << 8);
             const unsigned cell9 = cx + 9u * cy + 81u * cz;
             unsigned step_total;
@@ -636,11 +650,11 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
                 if ((owned >> bit) & 1u) {
                     const int id = id0 + __builtin_popcount(owned & ((1u << bit) - 1u));
                     if (!big) {   // at most 255 vertices: one window, every id has its byte
-                        L->q.vlist[id & 255] = (unsigned short)(desc | ((unsigned)a << 12));   // & 255: a count mismatch could never write outside the list
+                        L->vlist[id & 255] = (unsigned short)(desc | ((unsigned)a << 12));   // & 255: a count mismatch could never write outside the list
                         L->m.vtab[729 * a + cell9] = (unsigned char)id;
                     } else {
                         const int q = id - window;
-                        if (q >= 0 && q < kVlistCap) L->q.vlist[q] = (unsigned short)(desc | ((unsigned)a << 12));
+                        if (q >= 0 && q < kVlistCap) L->vlist[q] = (unsigned short)(desc | ((unsigned)a << 12));
                     }
                 }
             }
@@ -652,11 +666,11 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
                     const unsigned ed = tb->edge[e];
                     const int id = id0 + __builtin_popcount(owned & ((1u << e) - 1u));
                     if (!big) {
-                        L->q.vlist[id & 255] = (unsigned short)(desc + (ed & 0xFFFFu));
+                        L->vlist[id & 255] = (unsigned short)(desc + (ed & 0xFFFFu));
                         L->m.vtab[cell9 + (ed >> 16)] = (unsigned char)id;
                     } else {
                         const int q = id - window;
-                        if (q >= 0 && q < kVlistCap) L->q.vlist[q] = (unsigned short)(desc + (ed & 0xFFFFu));
+                        if (q >= 0 && q < kVlistCap) L->vlist[q] = (unsigned short)(desc + (ed & 0xFFFFu));
                     }
                     ex &= ex - 1u;
                 }
@@ -665,7 +679,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
         }
         return vrun;
     };
-    int n_vert = (ablate & 64) ? 0 : number_cells(0, true);
+    int n_vert = number_cells(0, true);
     if (n_vert > vert_budget) n_vert = vert_budget;  // never outside the block's slice of the vertex buffer
 
     // V: one lane per vertex, from the edge's low endpoint; position and normal leave as two 12-byte stores per lane
@@ -677,7 +691,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
             const int s = s0 + lane;
             if (s < n_w) {
                 float rec[kVertDwords];
-                eval_vertex<FAST>(tile, L->q.vlist[s], rec);
+                eval_vertex<FAST>(tile, L->vlist[s], rec);
                 float *p = out_vertices + (vert_base + (size_t)(window + s)) * kVertDwords;
                 if (!(ablate & 1)) {
                     *reinterpret_cast<v3u *>(p) = v3u{rec[0], rec[1], rec[2]};
@@ -697,7 +711,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
         for (int s0 = 0; s0 < pending; s0 += 64) {
             const int s = s0 + lane;
             if (s < pending) {
-                const unsigned sc = L->q.slot[s];
+                const unsigned sc = L->t.slot[s];
                 const unsigned cell = sc & 511u, trip = sc >> 9;
                 const unsigned e[3] = {trip & 15u, (trip >> 8) & 15u, (trip >> 4) & 15u};  // winding swap, MarchingCube.compute:147-157
                 int id[3];
@@ -709,7 +723,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
                     const unsigned b7 = (unsigned)((cell & 7u) == 7u) | ((unsigned)(((cell >> 3) & 7u) == 7u) << 1) | ((unsigned)((cell >> 6) == 7u) << 2);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const unsigned ow = s_own[e[k] * 8u + b7];                 // owner cell offset | owner-side edge id << 8
+                        const unsigned ow = s_own ? s_own[e[k] * 8u + b7] : owner_entry(e[k], b7);   // owner cell offset | owner-side edge id << 8 (no table: computed -- blocks of > 255 vertices are rare)
                         const unsigned vm = L->m.cellmap[cell + (ow & 0xFFu)];
                         id[k] = (int)((vm & 0xFFFFu) + (unsigned)__builtin_popcount((vm >> 16) & ((1u << (ow >> 8)) - 1u)));
                     }
@@ -731,11 +745,11 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
         const int idx = c0 + lane;
         const bool valid = idx < n_act;
         const unsigned cell = valid ? L->acell[idx] : 0u;
-        const u64 vw = valid ? s_vert[(ablate & 64) ? cell_case(tile, cell) : (unsigned)L->cases[cell]] : 0ull;   // ablate 64 (diagnostics) skips the numbering that leaves the cases
+        const u64 vw = valid ? s_vert[(unsigned)L->cases[cell]] : 0ull;   // the tile is gone: the slots lie over it
         const unsigned n = (unsigned)(vw >> 60);
         unsigned step_total;
         const unsigned pre_n = wave_prefix3(n, step_total);
-        unsigned *dst = L->q.slot + pending + pre_n;
+        unsigned *dst = L->t.slot + pending + pre_n;
 #pragma unroll
         for (unsigned i = 0; i < 5; ++i)
             if (i < n) dst[i] = cell | (((unsigned)(vw >> (12 * i)) & 0xFFFu) << 9);

@@ -110,8 +110,12 @@ __device__ __forceinline__ void wait_vm_at_most(int n, float (&t)[20], unsigned 
 //   stores are never waited for; !ASYNC is round 2's loop (kept for same-box A/Bs: tuning key "emit_async").
 //   ONCE (soup only): every welded vertex of a block is evaluated one time into LDS and the records are expanded from there
 //   (emit_block_once, emit_device.h); 53 KB of LDS per workgroup: three workgroups per CU.
-template <bool FAST, bool INDEXED, bool ASYNC, bool ONCE = false>
-__global__ __launch_bounds__(256, ONCE ? 3 : 4) void emit_kernel(BlockSpace sp, DeviceTables tb,
+//   WAVES: waves per workgroup.  The indexed output's per-wave LDS is small enough that the shared tables decide how many waves fit a CU:
+//   three-wave workgroups, six per CU = 18 waves (four-wave workgroups: 16); the kernel is latency-bound there (0.92 / 0.68 / 0.59 ms at
+//   8 / 12 / 16 waves).  Workgroups of more than 256 threads get fewer slots than their LDS would allow (measured, tools/_ab/occ2.hip:
+//   52 KB x 384 threads: two per CU where the occupancy query says three).
+template <bool FAST, bool INDEXED, bool ASYNC, bool ONCE = false, int WAVES = kWavesPerWg>
+__global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void emit_kernel(BlockSpace sp, DeviceTables tb,
                                                     const uint32_t *__restrict__ offsets,
                                                     const int32_t *__restrict__ active_list,
                                                     const uint32_t *__restrict__ totals, uint32_t capacity,
@@ -122,25 +126,29 @@ __global__ __launch_bounds__(256, ONCE ? 3 : 4) void emit_kernel(BlockSpace sp, 
 {
     static_assert(!(ONCE && INDEXED), "ONCE is a form of the soup");
     using Lds = typename std::conditional<INDEXED, EmitLdsIdx, typename std::conditional<ONCE, EmitLdsOnce, EmitLds2>::type>::type;
-    __shared__ Lds s_lds[kWavesPerWg];
+    __shared__ Lds s_lds[WAVES];
     __shared__ u64 s_vert[256];
     struct NoTables { unsigned char unused; };
-    __shared__ typename std::conditional<ONCE || INDEXED, OnceTables, NoTables>::type s_once[1];
-    __shared__ unsigned short s_own[INDEXED ? 96 : 1];   // (cube edge, which coordinates are 7) -> owner cell offset | owner-side edge id
+    __shared__ typename std::conditional<INDEXED, IdxTables, typename std::conditional<ONCE, OnceTables, NoTables>::type>::type s_once[1];
+    // (cube edge, which coordinates are 7) -> owner cell offset | owner-side edge id: a table for four-wave workgroups; three-wave ones compute
+    // it (blocks of more than 255 vertices only) -- their 26 832 bytes of LDS are 21 allocation granules of 1 280 bytes, six workgroups per CU
+    __shared__ unsigned short s_own_tab[INDEXED && WAVES != 3 ? 96 : 1];
+    const unsigned short *s_own = INDEXED && WAVES != 3 ? s_own_tab : nullptr;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    s_vert[threadIdx.x] = tb.vert_packed[threadIdx.x];
-    if (INDEXED && threadIdx.x < 96) s_own[threadIdx.x] = owner_entry(threadIdx.x >> 3, threadIdx.x & 7u);
-    if constexpr (ONCE || INDEXED) once_tables_init(&s_once[0], threadIdx.x);
+    for (int i = threadIdx.x; i < 256; i += 64 * WAVES) s_vert[i] = tb.vert_packed[i];
+    if (INDEXED && WAVES != 3 && threadIdx.x < 96) s_own_tab[threadIdx.x] = owner_entry(threadIdx.x >> 3, threadIdx.x & 7u);
+    if constexpr (INDEXED) idx_tables_init(&s_once[0], threadIdx.x);
+    else if constexpr (ONCE) once_tables_init(&s_once[0], threadIdx.x);
 #ifdef VTMC_DEBUG_POISON_LDS  // diagnostic build: NaN-fill LDS so any read of a never-written word shows up in the output
-    for (unsigned i = threadIdx.x; i < sizeof(s_lds) / 4; i += 256) reinterpret_cast<unsigned *>(s_lds)[i] = 0x7FC00000u;
+    for (unsigned i = threadIdx.x; i < sizeof(s_lds) / 4; i += 64 * WAVES) reinterpret_cast<unsigned *>(s_lds)[i] = 0x7FC00000u;
 #endif
     __syncthreads();
 
     // per-volume {vertices, triangles} (the array a multi-GPU caller all-gathers) from the scan's
     // offsets: a few lanes of the first workgroup instead of a dispatch of its own
     if (volume_counts && blockIdx.x == 0) {
-        for (int v = threadIdx.x; v < n_volumes; v += 256) {
+        for (int v = threadIdx.x; v < n_volumes; v += 64 * WAVES) {
             const long long lo = (long long)v * sp.bpv, hi = lo + sp.bpv;
             const uint32_t t = offsets[hi] - offsets[lo];
             volume_counts[2 * v] = INDEXED ? voffsets[hi] - voffsets[lo] : 3u * t;   // soup: 3 vertices per triangle (VoxelTerrain.cs:456-459)
@@ -155,6 +163,7 @@ __global__ __launch_bounds__(256, ONCE ? 3 : 4) void emit_kernel(BlockSpace sp, 
     Lds *L = &s_lds[wave];
     auto tile_of = [](Lds *l) -> float * {
         if constexpr (ONCE) return l->c.tile;
+        else if constexpr (INDEXED) return l->t.tile;
         else return l->tile;
     };
 
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(256, ONCE ? 3 : 4) void emit_kernel(BlockSpace sp, 
     const int ai_end = (int)((long long)n_active * (part + 1) / n_part);
     // the k-th block of this wave: rounds of (waves per XCD) groups, each wave takes 2^group_log2
     // consecutive list entries per round (x-adjacent blocks share 128-byte lines)
-    const int u = j * kWavesPerWg + wave, n_u = per_xcd * kWavesPerWg;
+    const int u = j * WAVES + wave, n_u = per_xcd * WAVES;
     auto entry = [&](int k) {
         const int r = k >> group_log2, g = k & ((1 << group_log2) - 1);
         return ai_begin + (((r * n_u + u) << group_log2) | g);
@@ -388,19 +397,28 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
                                uint32_t vert_capacity, void *vertices, void *indices, int n_cus, const Tuning &tune, unsigned *queue,
                                uint32_t *volume_counts, int n_volumes, hipStream_t stream)
 {
-    int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : 4;   // 39.9 KB of LDS, <= 128 VGPRs
+    const bool three = tune.emit_idx_waves == 3;   // three-wave workgroups: 26 832 B of LDS (21 granules of 1 280 B), six per CU = 18 waves (<= 96 VGPRs); four-wave ones: 35.2 KB, four per CU = 16
+    int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : (three ? 6 : 4);
     int wgs = n_cus * per_cu;
     wgs = (wgs + 7) & ~7;
     if (wgs > 8 + tune.emit_spare_wgs) wgs -= tune.emit_spare_wgs & ~7;
-    dim3 g(wgs), blk(256);
+    dim3 g(wgs), blk(three ? 192 : 256);
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
-#define VTMC_LAUNCH_IDX(F, A) hipLaunchKernelGGL((emit_kernel<F, true, A>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes)
-    if (tune.emit_fast_math) {
-        if (tune.emit_async) VTMC_LAUNCH_IDX(true, true);
-        else VTMC_LAUNCH_IDX(true, false);
+#define VTMC_LAUNCH_IDX(F, A, W) hipLaunchKernelGGL((emit_kernel<F, true, A, false, W>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes)
+    if (three) {
+        if (tune.emit_fast_math) {
+            if (tune.emit_async) VTMC_LAUNCH_IDX(true, true, 3);
+            else VTMC_LAUNCH_IDX(true, false, 3);
+        } else {
+            if (tune.emit_async) VTMC_LAUNCH_IDX(false, true, 3);
+            else VTMC_LAUNCH_IDX(false, false, 3);
+        }
+    } else if (tune.emit_fast_math) {
+        if (tune.emit_async) VTMC_LAUNCH_IDX(true, true, 4);
+        else VTMC_LAUNCH_IDX(true, false, 4);
     } else {
-        if (tune.emit_async) VTMC_LAUNCH_IDX(false, true);
-        else VTMC_LAUNCH_IDX(false, false);
+        if (tune.emit_async) VTMC_LAUNCH_IDX(false, true, 4);
+        else VTMC_LAUNCH_IDX(false, false, 4);
     }
 #undef VTMC_LAUNCH_IDX
     return hipGetLastError();

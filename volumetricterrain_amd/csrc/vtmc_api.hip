@@ -752,6 +752,7 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     else if (k == "emit_dynamic") ctx->tune.emit_dynamic = value;
     else if (k == "emit_async") ctx->tune.emit_async = value;
     else if (k == "emit_once") ctx->tune.emit_once = value;
+    else if (k == "emit_idx_waves") ctx->tune.emit_idx_waves = value;
     else if (k == "one_pass") ctx->tune.one_pass = value;
     else if (k == "one_pass_unit") ctx->tune.one_pass_unit = value;
     else if (k == "one_pass_depth") ctx->tune.one_pass_depth = value;

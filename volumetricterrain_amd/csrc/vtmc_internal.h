@@ -76,6 +76,7 @@ struct Tuning {
     int emit_async = 1;       // 1: tile prefetch and tickets outside the compiler's vmcnt bookkeeping, a block's stores are never waited for (emit_kernels.hip); 0: round 2's loop
     int emit_once = 1;        // 1 (soup, fast math): every welded vertex of a block is evaluated once into LDS, records expanded from there; 0: per triangle corner
     int emit_spare_wgs = 0;   // workgroups the emit launch leaves free (one per XCD: room for the collective's kernel beside it)
+    int emit_idx_waves = 4;   // indexed output: waves per emit workgroup (4: four workgroups = 16 waves per CU; 3: six = 18 -- measured no faster: the kernel is at its memory ceiling from 15 waves on)
     int one_pass = 0;         // 1 (soup, dense x-fastest batches): classify + scan + emit in ONE launch (onepass_kernels.hip); 0: three launches
     int one_pass_depth = 0;   // one-pass: bricks a wave classifies before it emits the oldest of them (1-3; 0: 2)
     int one_pass_prefetch = 0;   // one-pass: 1 = the next ticket is requested beside the last block of the brick being emitted (measured: +20 %, the held brick stalls the bricks behind it)
