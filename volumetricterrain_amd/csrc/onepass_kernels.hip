@@ -52,6 +52,17 @@ __device__ __forceinline__ void st_agent(T *p, T v)
 
 }  // namespace
 
+#ifdef VTMC_ONEPASS_TIMING   // diagnostic build: where a wave's time goes (100 MHz ticks summed over all waves, printed by the counts kernel)
+#define VTMC_T(i)                                   \
+    do {                                            \
+        const long long now_ = wall_clock64();      \
+        tacc[i] += now_ - tlast;                    \
+        tlast = now_;                               \
+    } while (0)
+#else
+#define VTMC_T(i) do { } while (0)
+#endif
+
 template <bool FAST>
 __global__ __launch_bounds__(256, 3) void onepass_kernel(BlockSpace sp, DeviceTables tb, OnePassCtrl ctl, uint32_t *__restrict__ offsets,
                                                                     float *__restrict__ out, uint32_t capacity, int nsegx, int n_bricks,
@@ -65,6 +76,9 @@ __global__ __launch_bounds__(256, 3) void onepass_kernel(BlockSpace sp, DeviceTa
     __shared__ unsigned char s_trinum[256];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef VTMC_ONEPASS_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+#endif
     s_vert[threadIdx.x] = tb.vert_packed[threadIdx.x];
     s_trinum[threadIdx.x] = tb.tri_num[threadIdx.x];
     once_tables_init(&s_once[0], threadIdx.x);
@@ -191,6 +205,7 @@ __global__ __launch_bounds__(256, 3) void onepass_kernel(BlockSpace sp, DeviceTa
         if (lane >= 16) incl += o;
         o = (unsigned)__shfl_up((int)incl, 32);
         if (lane >= 32) incl += o;
+        VTMC_T(1);   // rows + counts
         e.total = total;
         e.rows = rows;
         e.excl = incl - total;
@@ -238,6 +253,7 @@ __global__ __launch_bounds__(256, 3) void onepass_kernel(BlockSpace sp, DeviceTa
             }
             if (lane == 0 && !failed) st_agent(ctl.gstat + g, kOpInclusive | (e.group_excl + agg));
         }
+        VTMC_T(2);   // publication (+ the group's prefix if this brick completed it)
         return e;
     };
 
@@ -249,6 +265,16 @@ __global__ __launch_bounds__(256, 3) void onepass_kernel(BlockSpace sp, DeviceTa
         // The next ticket travels beside the END of this brick: beside its last block, or beside the look-back of a brick without
         // triangles.  Never earlier: until the ticket's brick is classified, no brick after it can be emitted.
         if (more && prefetch && e.brick_total == 0u) request();   // opt-in ("one_pass_prefetch"): measured slower
+        const Where at = locate(brick);
+        // the first block's tile travels beside the look-back wait; every later one beside the emission of the block before it
+        u64 act = __builtin_amdgcn_ballot_w64((lane & 7) == 0 && e.total != 0u);
+        if (ablate & 64) act = 0;   // diagnostics: no emission
+        float pre[20] = {};   // rows a block does not need keep whatever was there: never read
+        auto fetch = [&](int l8) {
+            const unsigned rmask = (unsigned)__builtin_amdgcn_readlane((int)e.rows, l8);
+            load_rows(reinterpret_cast<const char *>(at.base + at.segx * 64 + l8), rmask, pre);   // 8 cells per block: the block's first sample is l8
+        };
+        if (act) fetch(__builtin_ctzll(act));
         unsigned long long prefix = 0;
         if (!(ablate & 32)) {   // ablate 32 (diagnostics): no look-back -- every brick writes from offset 0
             unsigned w = lane < bi ? 0u : kOpPublished;
@@ -270,9 +296,9 @@ __global__ __launch_bounds__(256, 3) void onepass_kernel(BlockSpace sp, DeviceTa
             for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
             prefix = (e.have_group_excl ? e.group_excl : (gw & kOpValue)) + part;
         }
+        VTMC_T(3);   // look-back
         if (ablate & 128) prefix = 162ull * (unsigned)brick;   // diagnostics (with 32): no look-back, the stores spread over the real buffer
 
-        const Where at = locate(brick);
         const int bl = at.segx * 8 + (lane >> 3);
         if ((lane & 7) == 0 && bl < sp.nbx) offsets[at.bid0 + bl] = (uint32_t)(prefix + e.excl);
         if (brick == n_bricks - 1 && lane == 0) {
@@ -288,8 +314,6 @@ __global__ __launch_bounds__(256, 3) void onepass_kernel(BlockSpace sp, DeviceTa
         }
 
         // emit the brick's blocks, ascending
-        u64 act = __builtin_amdgcn_ballot_w64((lane & 7) == 0 && e.total != 0u);
-        if (ablate & 64) act = 0;   // diagnostics: no emission
         while (act) {
             const int l8 = __builtin_ctzll(act);
             act &= act - 1;
@@ -297,18 +321,16 @@ __global__ __launch_bounds__(256, 3) void onepass_kernel(BlockSpace sp, DeviceTa
             const int budget = __builtin_amdgcn_readlane((int)e.total, l8);
             const unsigned long long tri_base = prefix + (unsigned)__builtin_amdgcn_readlane((int)e.excl, l8);
             const unsigned rmask = (unsigned)__builtin_amdgcn_readlane((int)e.rows, l8);
-            if (tri_base + (unsigned long long)budget > (unsigned long long)capacity) continue;   // the host grows the buffer and runs the step again
-            const int b = l8 >> 3;
-            const float *src = at.base + at.segx * 64 + 8 * b;
-            float pre[20] = {};   // rows the block does not need stay 0: never read
-            load_rows(reinterpret_cast<const char *>(src), rmask, pre);
             VTMC_WAVE_SYNC();
             store_tile(pre);
+            if (act) fetch(__builtin_ctzll(act));
             VTMC_WAVE_SYNC();
-            const int bid = at.bid0 + at.segx * 8 + b;
+            VTMC_T(4);   // tile
+            if (tri_base + (unsigned long long)budget > (unsigned long long)capacity) continue;   // the host grows the buffer and runs the step again
+            const int bid = at.bid0 + at.segx * 8 + (l8 >> 3);
             if constexpr (FAST) emit_block_once<true>(L, s_vert, &s_once[0], (size_t)tri_base, budget, bid, out, lane, ablate, rmask, vm_unused);
             else emit_block_from_tile<false>(L, s_vert, (size_t)tri_base, budget, bid, out, lane, ablate, rmask, vm_unused);
-            VTMC_WAVE_SYNC();
+            VTMC_T(5);   // emission
         }
     };
 
@@ -323,6 +345,7 @@ __global__ __launch_bounds__(256, 3) void onepass_kernel(BlockSpace sp, DeviceTa
                 more = false;
                 break;
             }
+            VTMC_T(0);   // ticket
             const Entry x = classify_publish(b);
             if (n == 0) e0 = x;
             else e1 = x;
@@ -330,15 +353,32 @@ __global__ __launch_bounds__(256, 3) void onepass_kernel(BlockSpace sp, DeviceTa
         }
         if (n == 0 || failed) break;
         finish(e0);
+        VTMC_T(6);   // offsets, bookkeeping
         e0 = e1;
         --n;
     }
+#ifdef VTMC_ONEPASS_TIMING
+    VTMC_T(7);
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(ctl.err) + 2 + i, (unsigned long long)tacc[i]);
+#endif
 }
 
 // per-volume {vertices, triangles} (the array a multi-GPU caller all-gathers) from the offsets the one-pass kernel left
-__global__ void onepass_volume_counts_kernel(const uint32_t *__restrict__ offsets, int bpv, int n_volumes, uint32_t *__restrict__ volume_counts)
+__global__ void onepass_volume_counts_kernel(const uint32_t *__restrict__ offsets, int bpv, int n_volumes, uint32_t *__restrict__ volume_counts,
+                                             const unsigned long long *timing, int n_waves)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
+#ifdef VTMC_ONEPASS_TIMING
+    if (v == 0 && timing) {
+        unsigned long long tot = 0;
+        for (int i = 0; i < 8; ++i) tot += timing[i];
+        printf("onepass wave time [us per wave, %% ]: ticket %.1f (%.0f) rows+counts %.1f (%.0f) publish %.1f (%.0f) look-back %.1f (%.0f) tile %.1f (%.0f) emit %.1f (%.0f) rest %.1f (%.0f) tail %.1f (%.0f)\n",
+               timing[0] / 100.0 / n_waves, 100.0 * timing[0] / tot, timing[1] / 100.0 / n_waves, 100.0 * timing[1] / tot, timing[2] / 100.0 / n_waves, 100.0 * timing[2] / tot,
+               timing[3] / 100.0 / n_waves, 100.0 * timing[3] / tot, timing[4] / 100.0 / n_waves, 100.0 * timing[4] / tot, timing[5] / 100.0 / n_waves, 100.0 * timing[5] / tot,
+               timing[6] / 100.0 / n_waves, 100.0 * timing[6] / tot, timing[7] / 100.0 / n_waves, 100.0 * timing[7] / tot);
+    }
+#endif
     if (v >= n_volumes) return;
     const long long lo = (long long)v * bpv, hi = lo + bpv;
     const uint32_t t = offsets[hi] - offsets[lo];
@@ -387,7 +427,8 @@ hipError_t launch_onepass(const BlockSpace &sp, const DeviceTables &tb, void *ct
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (volume_counts && n_volumes > 0) {
-        hipLaunchKernelGGL(onepass_volume_counts_kernel, dim3((n_volumes + 255) / 256), dim3(256), 0, stream, offsets, sp.bpv, n_volumes, volume_counts);
+        hipLaunchKernelGGL(onepass_volume_counts_kernel, dim3((n_volumes + 255) / 256), dim3(256), 0, stream, offsets, sp.bpv, n_volumes, volume_counts,
+                           reinterpret_cast<const unsigned long long *>(c.err) + 2, wgs * 4);
         e = hipGetLastError();
     }
     return e;
