@@ -3,13 +3,15 @@
 // The three-launch path (classify_kernels.hip -> scan -> emit_kernels.hip) reads the samples of every block with triangles twice: the
 // classify pass streams the whole volume, the emit pass comes back for the 10^3 tiles (1.8 GB of 128-byte lines on the 1024^3 field,
 // long after the first pass has left the caches).  Here a wave classifies a brick (64 x 8 x 8 cells, classify_brick_column), learns where
-// its triangles go from a chained scan over the bricks (decoupled look-back, two levels), and emits the brick's blocks right away: the tile
-// rows come out of the L2 / Infinity Cache the wave has just filled, the counts never travel through memory, and a step is one launch.
+// its triangles go from a chained scan over the bricks (decoupled look-back, two levels), and emits the brick's blocks right away: the
+// counts never travel through memory and a step is one launch.  (The idea that the tile rows would come out of the caches the wave has
+// just filled did not survive the counters: see "Measured" below.)
 //
 //   * work distribution: persistent waves, one brick per ticket.  Eight ticket counters, one per XCD (blockIdx % 8: a speed heuristic
 //     only); counter x hands out the bricks of the units u = x, x + 8, ... in ascending order (a unit = `unit_bricks` consecutive bricks:
-//     a volume of the batch when that is a whole number of groups, so the bricks that share halo planes meet in one L2); a wave whose own
-//     counter has run dry takes from the next one.
+//     ONE 64-brick group by default.  Larger units would keep the bricks that share halo planes in one L2, but the chained scan needs
+//     every XCD at the same frontier of the brick order: 11 ms at 8 groups, 42 ms at a volume); a wave whose own counter has run dry
+//     takes from the next one.
 //   * order: triangles land in canonical order (block, cell, triangle): brick b's first triangle is the sum of the counts of all
 //     bricks before it.  Level 1: a brick publishes its count (bstat) the moment it is classified and adds it to its group's sum (gsum,
 //     64 bricks); the wave whose add completes the group publishes the group's aggregate (gstat), looks back over the earlier groups
@@ -23,9 +25,10 @@
 //   * classify ahead: a wave classifies and publishes the NEXT brick before it emits the current one, so the wait for the current
 //     brick's prefix (every lower brick classified + the trips of the group words through memory-side coherence) passes under useful
 //     work: 3.9 -> 2.0 ms on the 1024^3 field.
-// Measured (profiles/r03/experiments/one_pass_and_reread.txt): 2.03 ms against 1.75 ms for the three launches on the same box, 1.82-1.88 ms
-// with the look-back switched off -- the wave's serial chain (ticket, 83 row loads, count, publish, tile loads, emit) costs what the
-// saved second read gains.  The kernel is an opt-in (tuning key "one_pass"), bit-identical to the default path.
+// Measured (profiles/r03/experiments/one_pass_and_reread.txt): 2.03 ms against 1.75 ms for the three launches on the same box, 1.72-1.88 ms
+// with the look-back switched off; and 7.22 GB of memory-side reads against 4.50 + 1.82 GB: with all eight (non-coherent) L2s working along
+// the same stretch of the volume, halo planes and most tile rows are fetched by an XCD that did not read them first.  The kernel is an
+// opt-in (tuning key "one_pass"), bit-identical to the default path.
 #include "emit_device.h"
 
 #include <type_traits>
