@@ -178,7 +178,7 @@ def test_one_pass_matches_three_launches(ex, oracle_mod):
             assert vc[:, 1].sum() == T0 and np.array_equal(vc[:, 0], 3 * vc[:, 1])
             ms = ex.last_stage_ms()
             assert ms["total"] > 0 and ms["emit"] > 0
-        for n in ((40, 16, 24), (136, 8, 8), (200, 24, 8), (64, 64, 64)):     # exact mode (set above) against the oracle, bit for bit
+        for n in ((40, 16, 24), (136, 8, 8), (200, 24, 8), (264, 40, 24), (64, 64, 64)):     # exact mode (set above) against the oracle, bit for bit; 264 x 40 x 24: 75 bricks = one look-back group + a partial one
             g = fields.random_field(n, seed=n[0])
             want, want_offs, _ = oracle_mod.extract_grid(g, threads=8)
             assert ex.extract_grid(g) == len(want)
