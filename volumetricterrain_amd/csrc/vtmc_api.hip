@@ -416,6 +416,7 @@ int32_t vtmc_destroy(vtmc_ctx *ctx)
         release(*b);
     if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
     if (ctx->h_origins) (void)hipHostFree(ctx->h_origins);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->ev_origins) (void)hipEventDestroy(ctx->ev_origins);
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -470,11 +471,34 @@ int32_t vtmc_extract_grid(vtmc_ctx *ctx, const float *grid, int32_t nx, int32_t 
             // small dirty set on a large grid: gather tiles on the host exactly as BatchUpdate does
             // (VoxelTerrain.cs:341-361) so only B*4000 bytes cross PCIe instead of the whole grid
             if (stride_x <= 0 || stride_y <= 0 || stride_z <= 0) return fail(ctx, VTMC_ERR_INVALID_ARG, "strides must be positive");
-            std::vector<float> tiles((size_t)n_blocks * VTMC_TILE_SAMPLES);
+            // The tiles are gathered into PINNED memory of the context (grown on demand, kept): the upload is then one DMA straight from
+            // where the gather wrote, instead of the runtime's staged copy of a pageable vector (profiles/r03/dropin_route.txt).
+            const size_t tile_bytes = (size_t)n_blocks * VTMC_TILE_SAMPLES * sizeof(float);
+            std::vector<float> pageable;
+            float *tiles = nullptr;
+            if (tile_bytes <= ((size_t)256 << 20)) {
+                if (tile_bytes > ctx->h_stage_bytes) {
+                    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+                    ctx->h_stage = nullptr;
+                    ctx->h_stage_bytes = 0;
+                    const size_t want = std::max(tile_bytes + tile_bytes / 4, (size_t)1 << 20);
+                    if (hipHostMalloc((void **)&ctx->h_stage, want, hipHostMallocDefault) == hipSuccess) ctx->h_stage_bytes = want;
+                    else ctx->h_stage = nullptr, (void)hipGetLastError();
+                }
+                tiles = ctx->h_stage;
+            }
+            if (!tiles) {   // no pinned memory to be had (or a huge dirty set): the pageable route
+                try {
+                    pageable.resize((size_t)n_blocks * VTMC_TILE_SAMPLES);
+                } catch (const std::bad_alloc &) {
+                    return fail(ctx, VTMC_ERR_DEVICE, "out of host memory gathering %d tiles", n_blocks);
+                }
+                tiles = pageable.data();
+            }
             for (int32_t b = 0; b < n_blocks; ++b) {
                 const int32_t *p = block_list + 3 * (size_t)b;
                 const float *org = grid + 8 * ((int64_t)p[0] * stride_x + (int64_t)p[1] * stride_y + (int64_t)p[2] * stride_z);
-                float *t = tiles.data() + (size_t)b * VTMC_TILE_SAMPLES;
+                float *t = tiles + (size_t)b * VTMC_TILE_SAMPLES;
                 // the innermost loop walks the grid axis with the smallest stride (z for a C# float[,,]): the reads stay in one or two cache lines
                 if (stride_z < stride_x) {
                     for (int ix = 0; ix < 10; ++ix)
@@ -486,7 +510,7 @@ int32_t vtmc_extract_grid(vtmc_ctx *ctx, const float *grid, int32_t nx, int32_t 
                             for (int ix = 0; ix < 10; ++ix) t[ix + 10 * iy + 100 * iz] = org[ix * stride_x + iy * stride_y + iz * stride_z];
                 }
             }
-            return vtmc_extract_blocks(ctx, tiles.data(), n_blocks, tri_count);
+            return vtmc_extract_blocks(ctx, tiles, n_blocks, tri_count);   // blocking: the staging buffer is free again when it returns
         }
         if (int rc = upload_grid(ctx, grid, nx, ny, nz, stride_x, stride_y, stride_z)) return rc;
         if (int rc = ensure(ctx, ctx->list, sizeof(int32_t) * 3 * (size_t)std::max(n_blocks, 1))) return rc;
@@ -1026,6 +1050,7 @@ int32_t vtmc_density_fill_device_async(vtmc_ctx *ctx, const vtmc_density_params 
     if (ctx->origins_upload_pending) VTMC_HIP(ctx, hipEventSynchronize(ctx->ev_origins));   // the previous upload has left the staging words
     if (ctx->h_origins_bytes < org_bytes) {
         if (ctx->h_origins) (void)hipHostFree(ctx->h_origins);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
         ctx->h_origins = nullptr;
         ctx->h_origins_bytes = 0;
         VTMC_HIP(ctx, hipHostMalloc((void **)&ctx->h_origins, org_bytes, hipHostMallocDefault));

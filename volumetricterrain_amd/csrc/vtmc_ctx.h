@@ -48,6 +48,8 @@ struct vtmc_ctx {
         int dx = 0, dy = 0, dz = 0, n_volumes = 0;
         long long sv = 0;
     } sign_of;                      // which buffer / layout `signs` describes
+    float *h_stage = nullptr;       // pinned staging of host-gathered tiles (vtmc_extract_grid with a dirty list)
+    size_t h_stage_bytes = 0;
     int32_t *h_origins = nullptr;   // pinned staging of the sampler's chunk origins
     size_t h_origins_bytes = 0;
     hipEvent_t ev_origins = nullptr;   // behind the upload from h_origins
