@@ -74,10 +74,11 @@ def parse():
                          "k's result -- the device never waits for the host.  At N > 1 both contexts issue their all-gather through ONE "
                          "communicator (vtmc_comm_share), behind the emit kernel on the one stream everything runs on: for RCCL the same as a "
                          "single context.  1: every step ends with its host wait (the latency of an isolated step, also reported as step_latency_ms)")
-    ap.add_argument("--gather-stream", default="side", choices=["side", "main"],
-                    help="N > 1: the stream the all-gather and the copy of its result are queued on.  side (default): a second stream, ordered "
-                         "behind the extract's emit launch by an event -- the main stream never waits for the collective, it overlaps the next "
-                         "step's classify kernel; main: behind the emit kernel on the extract's own stream")
+    ap.add_argument("--gather-stream", default="main", choices=["side", "main"],
+                    help="N > 1: the stream the all-gather and the copy of its result are queued on.  main (default, the fewest moving parts: "
+                         "one stream, one communicator, program order): behind the emit kernel on the extract's own stream; side (opt-in until a "
+                         "world > 1 has run it): a second stream, ordered behind the extract's emit launch by an event -- the main stream never "
+                         "waits for the collective, it overlaps the next step's classify kernel")
     ap.add_argument("--gather-beside", action="store_true",
                     help="N > 1, opt-in: the all-gather on the context's second stream beside the emit kernel (tuning key gather_beside)")
     ap.add_argument("--no-dense", action="store_true", help="A/B: force the per-block classify kernel")
@@ -216,8 +217,8 @@ def init_distributed(args, torch, dist):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:   # main() starts the ranks itself when there is no launcher; a launcher with another world size is a mistake
+        raise SystemExit("bench.py: --gpus %d inside a launcher's world of %d ranks (WORLD_SIZE): refusing to print a line for another N" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the extraction path has no CPU fallback")
     # rehearsal hook for a one-GPU box: every rank on device 0, gloo instead of RCCL (which refuses
@@ -556,7 +557,7 @@ def run_grid(args, torch, dist):
             "kernels": per_kernel,
             "path_roofline": path,
             "allgather_ms": None if not gather_ms else {"avg": round(statistics.mean(gather_ms), 4), "max": round(max(gather_ms), 4),
-                                                     "note": "rank 0, HIP events from the end of the emit kernel to the end of the collective (sampled on every eighth step).  With --gather-stream side (default) the collective runs on a second stream and overlaps the next step's classify kernel: this is its own duration, not a cost of the step"},
+                                                     "note": "rank 0, HIP events from the end of the emit kernel to the end of the collective (sampled on every eighth step).  With --gather-stream main (default) the collective sits on the extract's stream, between this step's emit kernel and the next step's classify kernel; with --gather-stream side it runs on a second stream beside the latter"},
             "host_ms_per_step_beyond_kernels": round(ms_per_step - avg["total"], 4),
             "pipeline_depth": depth,
             "step_latency_ms": round(step_latency_ms, 4),
@@ -688,9 +689,31 @@ def emit_line(line):
         os.write(_REAL_STDOUT, data)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a CHILD `python -m torch.distributed.run`
+    (exactly the command the task statement gives) before this process has touched the GPU or imported torch, hand its stdout
+    through (rank 0's JSON line) and exit with its code.  A process that initialised the GPU is never replaced (no exec), and a
+    line with n_gpus = 1 is never printed for a run that asked for N."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env["VTMC_BENCH_SELF_LAUNCHED"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: starting %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     global _REAL_STDOUT
     args = parse()
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("VTMC_BENCH_SELF_LAUNCHED") != "1":
+        sys.exit(self_launch(args))
     # Libraries write to stdout on their own (RCCL prints a five-line version banner whenever a communicator is created): everything
     # but the JSON line is sent to stderr by pointing fd 1 there; the line itself goes to a duplicate of the original fd 1.
     sys.stdout.flush()

@@ -14,8 +14,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(cmd, env=None):
+def run(cmd, env=None, drop=()):
     e = dict(os.environ)
+    for k in drop:
+        e.pop(k, None)
     e.update(env or {})
     p = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-4000:]
@@ -78,3 +80,13 @@ def test_exchange_path_through_a_world_of_one_communicator():
     j2 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--pipeline", "2",
               "--gather-beside"], {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j2["pipeline_depth"] == 2 and j2["triangles_total"] == j["triangles_total"]
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it: bench.py starts the two ranks itself as a child process (before it
+    touches the GPU) and the line says n_gpus = 2 -- never a world of one under an N = 2 request."""
+    env = {"VTMC_BENCH_ONE_DEVICE": "1", "VTMC_BENCH_BACKEND": "gloo"}
+    j = run([sys.executable, "bench.py", "--gpus", "2", "--grid", "256", "--steps", "3", "--warmup", "1"], env,
+            drop=("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VTMC_BENCH_SELF_LAUNCHED"))
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["chunks_per_gpu"] == 4
+    assert abs(j["triangles_total"] - 2655156) < 2000

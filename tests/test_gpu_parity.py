@@ -13,8 +13,10 @@ pytestmark = pytest.mark.gpu
 ATOL = 1e-5  # north_star tolerance for positions / normals
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def ex():
+    """A fresh context per test: a test that leaves a context in a bad state (or a host-side slip in one auxiliary entry point)
+    costs that one test.  What a shared, long-lived context goes through is tests/test_lifecycle.py's subject."""
     import torch
     assert torch.cuda.is_available(), "these tests need the MI355X"
     import volumetricterrain_amd as vt

@@ -1,0 +1,140 @@
+"""One context, the literal drop-in call sequence mixed with every auxiliary entry point that owns
+pinned or device staging of its own (VoxelTerrain.cs:341-361 -> vtmc_extract_grid with a dirty list
+is the route being protected).
+
+Round 3 shipped a double free of the pinned tile staging: a sampler fill regrowing its origin
+staging freed the tile staging and left pointer and size standing; the next small dirty-list extract
+gathered into freed memory.  The sequence below is the one that exposed it, followed by the other
+owners of context state (terrain, chunk files, indexed output), each step checked against the oracle.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+
+
+def _same(got, want, atol=ATOL):
+    assert len(got) == len(want)
+    assert np.array_equal(got["block"], want["block"])
+    for f in ("p0", "p1", "p2", "n0", "n1", "n2"):
+        # a zero gradient gives NaN normals in the reference too (SampleNormal.compute:32, normalize of a zero vector): same lanes, please
+        nan_w = np.isnan(want[f])
+        assert np.array_equal(np.isnan(got[f]), nan_w), "NaN pattern differs in " + f
+        assert np.abs(np.where(nan_w, 0, got[f]) - np.where(nan_w, 0, want[f])).max(initial=0.0) <= atol, f
+
+
+def test_one_context_through_every_owner_of_staging(oracle_mod, tmp_path):
+    import torch
+    import volumetricterrain_amd as vt
+    from volumetricterrain_amd import chunkfile
+    assert torch.cuda.is_available()
+    g = oracle_mod.density_volume("perlin3d", 64)
+    blocks = oracle_mod.all_blocks(64, 64, 64)
+    rng = np.random.default_rng(11)
+    sel7 = blocks[rng.permutation(len(blocks))[:7]]
+    want7, offs7, _ = oracle_mod.extract_grid(g, sel7)
+    ex = vt.Extractor(0)
+    try:
+        # 1. a 7-block dirty list: host tile gather into the context's pinned staging
+        assert ex.extract_grid(g, sel7) == len(want7)
+        got, offs = ex.read_triangles()
+        assert np.array_equal(offs, offs7)
+        _same(got, want7)
+        # 2. sampler fills with a growing number of volumes: the origin staging regrows twice
+        dim = 34
+        prm = vt.density_params("perlin3d", 64)
+        for n_vol in (1, 3, 9):
+            orgs = [(8 * v, 0, 3 * v) for v in range(n_vol)]
+            d = torch.empty(n_vol * dim ** 3, dtype=torch.float32, device="cuda")
+            ex.density_fill_device(prm, orgs, (dim, dim, dim), (1, dim, dim * dim), dim ** 3, d.data_ptr())
+            host = d.cpu().numpy().reshape(n_vol, dim, dim, dim)
+            for v, o in enumerate(orgs):
+                want = oracle_mod.density_volume("perlin3d", 64, origin=o, dims=(dim, dim, dim))
+                assert np.abs(host[v].transpose(2, 1, 0) - want).max() <= 2e-6
+        # 3. the dirty-list route again, on the staging the fills must not have touched: same bytes as before
+        assert ex.extract_grid(g, sel7) == len(want7)
+        got2, offs2 = ex.read_triangles()
+        assert np.array_equal(offs2, offs7) and got2.tobytes() == got.tobytes()
+        # 4. a larger dirty list (staging regrows), then a small one again
+        sel40 = blocks[rng.permutation(len(blocks))[:40]]
+        want40, offs40, _ = oracle_mod.extract_grid(g, sel40)
+        big = oracle_mod.density_volume("perlin3d", 128)
+        bb = oracle_mod.all_blocks(128, 128, 128)
+        sel500 = bb[rng.permutation(len(bb))[:500]]
+        want500, offs500, _ = oracle_mod.extract_grid(big, sel500, threads=8)
+        assert ex.extract_grid(big, sel500) == len(want500)
+        got, offs = ex.read_triangles()
+        assert np.array_equal(offs, offs500)
+        _same(got, want500)
+        assert ex.extract_grid(g, sel40) == len(want40)
+        got, offs = ex.read_triangles()
+        assert np.array_equal(offs, offs40)
+        _same(got, want40)
+        # 5. the resident terrain on the same context: Init, an add and an erode, dirty blocks and mesh against the oracle
+        t = oracle_mod.Terrain(32, 16, 24, seed=3)
+        ex.terrain_init(32, 16, 24, seed=3)
+        specs = [vt.PlaneModifier(5.375, (0, 0), (40, 40), True), vt.SphereModifier((12.0, 6.0, 10.0), 4.5, False)]
+        ospecs = [oracle_mod.plane_modifier(5.375, (0, 0), (40, 40), True), oracle_mod.sphere_modifier((12.0, 6.0, 10.0), 4.5, False)]
+        for m, om in zip(specs, ospecs):
+            dirty = t.update([om])
+            nd, T = ex.terrain_update([m])
+            assert nd == len(dirty) and np.array_equal(ex.terrain_dirty_blocks(), dirty)
+            assert np.array_equal(ex.terrain_read_samples().view(np.uint32), t.grid.view(np.uint32))
+            want, woffs, _ = oracle_mod.extract_grid(t.grid, dirty)
+            assert T == len(want)
+            got, offs = ex.read_triangles()
+            assert np.array_equal(offs, woffs)
+            _same(got, want)
+        # 6. a chunk written from a device batch and read back (soup, then indexed), on the same context
+        c, cd = 32, 34
+        chunk = oracle_mod.density_volume("perlin3d", 128, origin=(32, 0, 64), dims=(cd, cd, cd))
+        dchunk = torch.from_numpy(np.ascontiguousarray(chunk.transpose(2, 1, 0))).cuda()
+        want, woffs, _ = oracle_mod.extract_grid(chunk)
+        for indexed in (False, True):
+            ex.set_output_mode(indexed)
+            assert ex.extract_volumes_device(dchunk.data_ptr(), (c, c, c), (1, cd, cd * cd), 1, 0) == len(want)
+            path = tmp_path / ("c%d.vtchunk" % indexed)
+            ex.chunk_write(path, 0, (32, 0, 64), with_samples=True)
+            f = chunkfile.read_chunk(path)
+            assert np.array_equal(f["tri_offsets"], woffs.astype(np.uint32))
+            view = ex.chunk_read(path)
+            assert view.n_triangles == len(want)
+            if not indexed:
+                _same(f["triangles"], want)
+        ex.set_output_mode(False)
+        # 7. and the drop-in route once more at the end: still the first answer
+        assert ex.extract_grid(g, sel7) == len(want7)
+        got3, offs3 = ex.read_triangles()
+        assert np.array_equal(offs3, offs7)
+        _same(got3, want7)
+    finally:
+        ex.close()   # destroy: every staging buffer is freed exactly once (a double free surfaces as a failure in the NEXT test's create)
+    with vt.Extractor(0) as e2:   # the runtime is still healthy after the teardown
+        assert e2.extract_grid(g, sel7) == len(want7)
+
+
+def test_a_stale_runtime_error_is_not_blamed_on_the_next_launch(oracle_mod):
+    """The HIP runtime keeps one sticky last-error word per thread.  A failure nobody consumed (here: provoked on purpose through
+    torch's own runtime calls) must not turn the library's next launch into an error (vtmc_internal.h: launch_begin / launch_end)."""
+    import ctypes
+    import torch
+    import volumetricterrain_amd as vt
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    g = oracle_mod.density_volume("perlin3d", 32)
+    want, _, _ = oracle_mod.extract_grid(g)
+    with vt.Extractor(0) as ex:
+        assert ex.extract_grid(g) == len(want)
+        assert hip.hipFree(ctypes.c_void_p(0x1000)) != 0          # an invalid free: leaves hipErrorInvalidValue behind
+        assert ex.extract_grid(g) == len(want)                    # classify / scan / emit launches do not inherit it
+        assert hip.hipFree(ctypes.c_void_p(0x1000)) != 0
+        dim = 34
+        d = torch.empty(dim ** 3, dtype=torch.float32, device="cuda")
+        ex.density_fill_device(vt.density_params("perlin3d", 32), [[0, 0, 0]], (dim, dim, dim), (1, dim, dim * dim), 0, d.data_ptr())
+        assert hip.hipFree(ctypes.c_void_p(0x1000)) != 0
+        ex.terrain_init(16, 16, 16, seed=2)
+        assert hip.hipFree(ctypes.c_void_p(0x1000)) != 0
+        nd, T = ex.terrain_update([vt.PlaneModifier(4.5, (0, 0), (20, 20), True)])
+        assert T == 2 * 16 * 16

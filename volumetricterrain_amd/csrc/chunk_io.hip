@@ -138,6 +138,7 @@ int32_t vtmc_chunk_write(vtmc_ctx *ctx, const char *path, int32_t volume, const 
     char *img = (char *)ctx->chunk_image.p;
     VTMC_HIP(ctx, hipMemsetAsync(img, 0, l.total, st));  // padding bytes are zero, as chunkfile.py writes them
     VTMC_HIP(ctx, hipMemcpyAsync(img, &h, sizeof h, hipMemcpyHostToDevice, st));
+    launch_begin();   // the pack launches below report their own status, nothing older
     if (with_samples) {
         const int dx = h.cells[0] + 2, dy = h.cells[1] + 2, dz = h.cells[2] + 2;
         const long long n = (long long)dx * dy * dz;
@@ -160,7 +161,7 @@ int32_t vtmc_chunk_write(vtmc_ctx *ctx, const char *path, int32_t volume, const 
         hipLaunchKernelGGL(pack_triangles_kernel, dim3(grid_for(nd)), dim3(256), 0, st, (const uint32_t *)ctx->tris.p + 19ll * span[0], nd,
                            (uint32_t)b0, (uint32_t *)(img + l.triangles));
     }
-    VTMC_HIP(ctx, hipGetLastError());
+    VTMC_HIP(ctx, launch_end());
     std::vector<char> host;
     try {   // nothing is thrown through the C boundary
         host.resize(l.total);

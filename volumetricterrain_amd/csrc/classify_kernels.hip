@@ -444,9 +444,10 @@ hipError_t launch_classify_blocks(const BlockSpace &sp, const DeviceTables &tb, 
     int cap = n_cus * 8;
     if (wgs > cap) wgs = cap;
     if (wgs < 1) wgs = 1;
+    launch_begin();
     hipLaunchKernelGGL(classify_blocks_kernel, dim3(wgs), dim3(256), 0, stream, sp, tb, counts, cases_or_null, vcounts_or_null, scan_ctrl,
                        n_scan_ctrl);
-    return hipGetLastError();
+    return launch_end();
 }
 
 hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
@@ -465,6 +466,7 @@ hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, u
     // faster with fewer (each wave already keeps 81 row loads in flight).  Unused dynamic LDS is what caps it.
     const size_t dyn = wgs_per_cu > 0 && wgs_per_cu < 8 ? (size_t)(160 * 1024 / wgs_per_cu - 1024) & ~(size_t)255 : 0;
     const dim3 g((unsigned)n_wgs), b(256);
+    launch_begin();
     if (signs.words && !lane_is_z) {   // instruction-bound variant: no residency cap
         if (vcounts_or_null)
             hipLaunchKernelGGL((classify_dense_kernel<true, true>), g, b, 0, stream, sp, tb, counts, vcounts_or_null, nsegx, (int)n_bricks, (int)n_wgs,
@@ -478,7 +480,7 @@ hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, u
     else
         hipLaunchKernelGGL((classify_dense_kernel<false, false>), g, b, dyn, stream, sp, tb, counts, vcounts_or_null, nsegx, (int)n_bricks, (int)n_wgs,
                            ablate, scan_ctrl, n_scan_ctrl, signs, lane_is_z);
-    return hipGetLastError();
+    return launch_end();
 }
 
 hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list, unsigned long long *ctrl,
@@ -488,13 +490,14 @@ hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *off
     const int n_tiles = (n_blocks + kScanTile - 1) / kScanTile;
     unsigned long long *vstatus = ctrl + scan_ctrl_words(n_blocks);   // the second half of the control words
     const int tpv = (volume_counts_or_null && bpv > 0 && bpv % kScanTile == 0) ? bpv / kScanTile : 0;
+    launch_begin();
     if (vcounts_or_null)
         hipLaunchKernelGGL((scan_fused_kernel<true>), dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, offsets, active_list, ctrl, totals,
                            host_totals, zero_words, n_zero, vcounts_or_null, voffsets, vstatus, vtotals, volume_counts_or_null, tpv);
     else
         hipLaunchKernelGGL((scan_fused_kernel<false>), dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, offsets, active_list, ctrl, totals,
                            host_totals, zero_words, n_zero, nullptr, nullptr, nullptr, nullptr, volume_counts_or_null, tpv);
-    return hipGetLastError();
+    return launch_end();
 }
 
 }  // namespace vtmc

@@ -27,6 +27,7 @@ static constexpr ncclResult_t ncclSuccess = 0;
 static constexpr ncclDataType_t ncclUint32 = 3;
 static constexpr int NCCL_UNIQUE_ID_BYTES = 128;
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -41,6 +42,8 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    int version = 0;
     std::string error;
 };
 
@@ -65,8 +68,16 @@ const RcclApi &rccl()
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
         a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
-        if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString) {
-            a.error = "librccl.so.1 lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+        a.GetVersion = (decltype(a.GetVersion))dlsym(a.handle, "ncclGetVersion");
+        if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString || !a.GetVersion) {
+            a.error = "librccl.so.1 lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclGetVersion";
+            a.handle = nullptr;
+            return;
+        }
+        // the declarations above are the NCCL 2.x ABI (ncclUint32 = 3, a 128-byte id passed by value): anything else is refused, not guessed at.
+        // Version code: major * 10000 + minor * 100 + patch from 2.9 on, major * 1000 + ... before.
+        if (a.GetVersion(&a.version) != ncclSuccess || a.version < 2000 || (a.version >= 10000 && a.version / 10000 != 2)) {
+            a.error = "librccl.so.1 reports version code " + std::to_string(a.version) + ": this library is written against the NCCL 2.x ABI";
             a.handle = nullptr;
         }
     });
@@ -84,20 +95,51 @@ const RcclApi &rccl()
 }  // namespace
 
 namespace vtmc {
+namespace {
+// every collective a context has queued through its communicator has finished: its own streams, a queued extract's stream, and -- through
+// the event recorded behind the last all-gather -- whatever stream the caller handed in (bench.py's side stream)
+void drain_collectives(vtmc_ctx *ctx)
+{
+    if (ctx->gather_recorded && ctx->ev_last_gather) quiet(hipEventSynchronize(ctx->ev_last_gather));
+    ctx->gather_recorded = false;
+    if (ctx->comm_stream) quiet(hipStreamSynchronize(ctx->comm_stream));
+    if (ctx->pending.active && ctx->pending.stream) quiet(hipStreamSynchronize(ctx->pending.stream));
+    if (ctx->stream) quiet(hipStreamSynchronize(ctx->stream));
+}
+}  // namespace
+
+// Contexts that share a communicator (vtmc_comm_share) are driven by ONE host thread -- their collectives must be in one program order
+// anyway -- so the owner's borrower list needs no lock.
 void comm_release(vtmc_ctx *ctx)
 {
-    if (ctx && ctx->comm) {
-        // no collective of this communicator may still be queued when it is destroyed
-        if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
-        if (ctx->pending.active && ctx->pending.stream) (void)hipStreamSynchronize(ctx->pending.stream);   // a queued extract's collective
-        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (!ctx || !ctx->comm) return;
+    quiet(hipSetDevice(ctx->device));
+    drain_collectives(ctx);   // no collective of this communicator may still be queued when it is destroyed
+    if (ctx->comm_borrowed) {   // a borrower leaves: the owner forgets it, the communicator stays
+        if (vtmc_ctx *o = ctx->comm_owner) {
+            auto &v = o->comm_borrowers;
+            v.erase(std::remove(v.begin(), v.end(), ctx), v.end());
+        }
+    } else {
+        // the owner goes first (e.g. the garbage collector's order): every borrower is drained and detached -- its next
+        // vtmc_allgather_volume_counts answers VTMC_ERR_NO_RESULT instead of using a destroyed communicator
+        for (vtmc_ctx *b : ctx->comm_borrowers) {
+            drain_collectives(b);
+            b->comm = nullptr;
+            b->comm_borrowed = false;
+            b->comm_owner = nullptr;
+            b->comm_world = 1;
+            b->comm_rank = 0;
+        }
+        ctx->comm_borrowers.clear();
         const RcclApi &a = rccl();
-        if (a.handle && !ctx->comm_borrowed) (void)a.CommDestroy((ncclComm_t)ctx->comm);
-        ctx->comm_borrowed = false;
-        ctx->comm = nullptr;
-        ctx->comm_world = 1;
-        ctx->comm_rank = 0;
+        if (a.handle) (void)a.CommDestroy((ncclComm_t)ctx->comm);
     }
+    ctx->comm_borrowed = false;
+    ctx->comm_owner = nullptr;
+    ctx->comm = nullptr;
+    ctx->comm_world = 1;
+    ctx->comm_rank = 0;
 }
 }  // namespace vtmc
 
@@ -144,6 +186,8 @@ int32_t vtmc_comm_share(vtmc_ctx *ctx, vtmc_ctx *owner)
     comm_release(ctx);
     ctx->comm = owner->comm;
     ctx->comm_borrowed = true;
+    ctx->comm_owner = owner;
+    owner->comm_borrowers.push_back(ctx);
     ctx->comm_rank = owner->comm_rank;
     ctx->comm_world = owner->comm_world;
     return VTMC_OK;
@@ -203,6 +247,10 @@ int32_t vtmc_allgather_volume_counts(vtmc_ctx *ctx, uint32_t *d_all_counts, int3
         send = ctx->comm_send.p;
     }
     VTMC_NCCL(ctx, a, a.AllGather(send, d_all_counts, words, ncclUint32, (ncclComm_t)ctx->comm, gs));
+    // behind the collective, on whatever stream it went to: comm_release waits for this before the communicator is destroyed
+    if (!ctx->ev_last_gather) VTMC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_last_gather, hipEventDisableTiming));
+    VTMC_HIP(ctx, hipEventRecord(ctx->ev_last_gather, gs));
+    ctx->gather_recorded = true;
     if (beside) {
         VTMC_HIP(ctx, hipEventRecord(ctx->ev_gather, gs));
         VTMC_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_gather, 0));

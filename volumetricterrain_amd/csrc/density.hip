@@ -406,6 +406,7 @@ hipError_t launch_density(const DensityLaunch &dl, const unsigned char *d_perm, 
         const long long n_wgs = n_plane_wgs * n_seg * dl.n_volumes;
         const long long n_rows = (long long)dl.n_volumes * n_steps;
         if (n_wgs <= 0 || n_wgs > 0x7fffffffll || n_rows > 0x7fffffffll) return hipErrorInvalidValue;
+        launch_begin();
         hipLaunchKernelGGL(density_row_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, dl, d_origins, 2,
                            n_steps, seg_len, d_rows);
         // residency cap (tuning key "density_wgs_per_cu"): unused dynamic LDS leaves wave slots, registers and LDS to the kernels of
@@ -427,14 +428,15 @@ hipError_t launch_density(const DensityLaunch &dl, const unsigned char *d_perm, 
             VTMC_COL(1) VTMC_COL(2) VTMC_COL(3) VTMC_COL(4) VTMC_COL(5) VTMC_COL(6) VTMC_COL(7) VTMC_COL(8)
         }
 #undef VTMC_COL
-        return hipGetLastError();
+        return launch_end();
     }
     const int nseg = (dfast + 255) / 256;
     long long n_wgs = (long long)dl.n_volumes * dslow * dl.dy * nseg;
     if (n_wgs <= 0 || n_wgs > 0x7fffffffll) return hipErrorInvalidValue;
+    launch_begin();
     hipLaunchKernelGGL(density_generic_kernel, dim3((unsigned)n_wgs), dim3(256), 0, stream, dl, d_perm, d_origins, d_out,
                        fast_is_z, nseg);
-    return hipGetLastError();
+    return launch_end();
 }
 
 size_t density_rows_bytes(int n_volumes, int dy, int dz) { return (size_t)n_volumes * (size_t)(dy > dz ? dy : dz) * kRowDwords * sizeof(float); }

@@ -378,6 +378,7 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
     dim3 g(wgs), blk(256);
     float *o = (float *)triangles;
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
+    launch_begin();
 #define VTMC_LAUNCH_SOUP(F, A, ...) hipLaunchKernelGGL((emit_kernel<F, false, A, ##__VA_ARGS__>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes)
     if (once) VTMC_LAUNCH_SOUP(true, true, true);
     else if (tune.emit_fast_math) {
@@ -388,7 +389,7 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
         else VTMC_LAUNCH_SOUP(false, false);
     }
 #undef VTMC_LAUNCH_SOUP
-    return hipGetLastError();
+    return launch_end();
 }
 
 hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets, const uint32_t *voffsets,
@@ -404,6 +405,7 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
     if (wgs > 8 + tune.emit_spare_wgs) wgs -= tune.emit_spare_wgs & ~7;
     dim3 g(wgs), blk(three ? 192 : 256);
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
+    launch_begin();
 #define VTMC_LAUNCH_IDX(F, A, W) hipLaunchKernelGGL((emit_kernel<F, true, A, false, W>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes)
     if (three) {
         if (tune.emit_fast_math) {
@@ -421,7 +423,7 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
         else VTMC_LAUNCH_IDX(false, false, 4);
     }
 #undef VTMC_LAUNCH_IDX
-    return hipGetLastError();
+    return launch_end();
 }
 
 }  // namespace vtmc

@@ -421,18 +421,19 @@ hipError_t launch_onepass(const BlockSpace &sp, const DeviceTables &tb, void *ct
     int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : (tune.emit_fast_math ? 3 : 4);
     int wgs = (n_cus * per_cu + 7) & ~7;
     const dim3 g(wgs), blk(256);
+    launch_begin();
     if (tune.emit_fast_math)
         hipLaunchKernelGGL((onepass_kernel<true>), g, blk, 0, stream, sp, tb, c, offsets, (float *)triangles, capacity, nsegx, (int)n_bricks, unit, totals,
                            host_totals, tune.classify_ablate, tune.emit_ablate, depth, tune.one_pass_prefetch);
     else
         hipLaunchKernelGGL((onepass_kernel<false>), g, blk, 0, stream, sp, tb, c, offsets, (float *)triangles, capacity, nsegx, (int)n_bricks, unit, totals,
                            host_totals, tune.classify_ablate, tune.emit_ablate, depth, tune.one_pass_prefetch);
-    e = hipGetLastError();
+    e = launch_end();
     if (e != hipSuccess) return e;
     if (volume_counts && n_volumes > 0) {
         hipLaunchKernelGGL(onepass_volume_counts_kernel, dim3((n_volumes + 255) / 256), dim3(256), 0, stream, offsets, sp.bpv, n_volumes, volume_counts,
                            reinterpret_cast<const unsigned long long *>(c.err) + 2, wgs * 4);
-        e = hipGetLastError();
+        e = launch_end();
     }
     return e;
 }

@@ -141,17 +141,19 @@ hipError_t launch_terrain_fill(float *grid, long long n, uint64_t seed, int n_cu
     long long wgs = (n + 255) / 256;
     if (wgs > (long long)n_cus * 16) wgs = (long long)n_cus * 16;
     if (wgs < 1) wgs = 1;
+    launch_begin();
     hipLaunchKernelGGL(terrain_fill_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, grid, n, seed);
-    return hipGetLastError();
+    return launch_end();
 }
 
 hipError_t launch_terrain_modify(float *grid, const TerrainShape &sh, const TerrainModifierArgs &m, hipStream_t stream)
 {
     if (m.dx <= 0 || m.dy <= 0 || m.dz <= 0) return hipSuccess;
     if ((m.dz + 3) / 4 > 65535 || (m.dy + kYRun - 1) / kYRun > 65535) return hipErrorInvalidValue;
+    launch_begin();
     hipLaunchKernelGGL(terrain_modify_kernel, dim3((unsigned)((m.dx + 63) / 64), (unsigned)((m.dz + 3) / 4), (unsigned)((m.dy + kYRun - 1) / kYRun)),
                        dim3(64, 4, 1), 0, stream, grid, sh, m);
-    return hipGetLastError();
+    return launch_end();
 }
 
 }  // namespace vtmc

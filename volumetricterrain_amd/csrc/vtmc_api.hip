@@ -28,6 +28,8 @@ typedef VtmcDevBuf DevBuf;
 
 namespace {
 thread_local std::string g_create_error;
+// pinned tile staging a context keeps between dirty-list calls; anything larger is given back by the next small call
+constexpr size_t kStageKeepBytes = (size_t)32 << 20;
 }  // namespace
 
 namespace vtmc {
@@ -60,9 +62,18 @@ int ensure(vtmc_ctx *ctx, DevBuf &b, size_t bytes)
 
 void release(DevBuf &b)
 {
-    if (b.p) (void)hipFree(b.p);
+    if (b.p) quiet(hipFree(b.p));
     b.p = nullptr;
     b.bytes = 0;
+}
+
+// Pinned staging is freed in ONE place, and pointer and size are cleared together: a buffer freed with its size left standing
+// is written to by the next call that finds it "large enough" (round 3's double free).
+void release_pinned(void **p, size_t *bytes)
+{
+    if (*p) quiet(hipHostFree(*p));
+    *p = nullptr;
+    if (bytes) *bytes = 0;
 }
 
 }  // namespace vtmc
@@ -406,25 +417,26 @@ int32_t vtmc_create(int32_t device, vtmc_ctx **out_ctx)
 int32_t vtmc_destroy(vtmc_ctx *ctx)
 {
     if (!ctx) return VTMC_OK;
-    (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    quiet(hipSetDevice(ctx->device));
+    if (ctx->stream) quiet(hipStreamSynchronize(ctx->stream));
     comm_release(ctx);
     for (DevBuf *b : {&ctx->d_vert, &ctx->d_trinum, &ctx->counts, &ctx->offsets, &ctx->active, &ctx->partials, &ctx->totals,
                       &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->yrows, &ctx->signs, &ctx->terrain, &ctx->heightmap,
                       &ctx->vcounts, &ctx->voffsets, &ctx->vtotals, &ctx->verts, &ctx->indices, &ctx->chunk_image,
                       &ctx->comm_send})
         release(*b);
-    if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
-    if (ctx->h_origins) (void)hipHostFree(ctx->h_origins);
-    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-    if (ctx->ev_origins) (void)hipEventDestroy(ctx->ev_origins);
+    release_pinned((void **)&ctx->h_totals, nullptr);
+    release_pinned((void **)&ctx->h_origins, &ctx->h_origins_bytes);
+    release_pinned((void **)&ctx->h_stage, &ctx->h_stage_bytes);
+    if (ctx->ev_origins) quiet(hipEventDestroy(ctx->ev_origins));
     for (auto &ev : ctx->ev)
-        if (ev) (void)hipEventDestroy(ev);
+        if (ev) quiet(hipEventDestroy(ev));
     for (auto &ev : ctx->ev_fill)
-        if (ev) (void)hipEventDestroy(ev);
-    if (ctx->ev_gather) (void)hipEventDestroy(ctx->ev_gather);
-    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        if (ev) quiet(hipEventDestroy(ev));
+    if (ctx->ev_gather) quiet(hipEventDestroy(ctx->ev_gather));
+    if (ctx->ev_last_gather) quiet(hipEventDestroy(ctx->ev_last_gather));
+    if (ctx->comm_stream) quiet(hipStreamDestroy(ctx->comm_stream));
+    if (ctx->stream) quiet(hipStreamDestroy(ctx->stream));
     delete ctx;
     return VTMC_OK;
 }
@@ -444,7 +456,11 @@ int32_t vtmc_extract_blocks(vtmc_ctx *ctx, const float *samples, int32_t n_block
     // the tile buffer is a batch of n_blocks volumes of one 8^3 block each
     BlockSpace sp = dense_space((const float *)ctx->input.p, 8, 8, 8, 1, 10, 100, n_blocks, VTMC_TILE_SAMPLES);
     int64_t T = 0;
-    if (int rc = extract_core(ctx, sp, 0, 0, ctx->stream, &T)) return rc;
+    if (int rc = extract_core(ctx, sp, 0, 0, ctx->stream, &T)) {
+        // the caller's `samples` are only borrowed for this call: a failure behind the asynchronous upload must not return while the DMA still reads them
+        if (n_blocks > 0) quiet(hipStreamSynchronize(ctx->stream));
+        return rc;
+    }
     if (tri_count) *tri_count = (int32_t)T;
     return VTMC_OK;
 }
@@ -477,13 +493,13 @@ int32_t vtmc_extract_grid(vtmc_ctx *ctx, const float *grid, int32_t nx, int32_t 
             std::vector<float> pageable;
             float *tiles = nullptr;
             if (tile_bytes <= ((size_t)256 << 20)) {
-                if (tile_bytes > ctx->h_stage_bytes) {
-                    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-                    ctx->h_stage = nullptr;
-                    ctx->h_stage_bytes = 0;
+                // kept between calls up to kStageKeepBytes; a larger one (a one-off big edit) is trimmed back by the next small call
+                if (tile_bytes > ctx->h_stage_bytes || (ctx->h_stage_bytes > kStageKeepBytes && tile_bytes <= kStageKeepBytes / 4)) {
+                    release_pinned((void **)&ctx->h_stage, &ctx->h_stage_bytes);
                     const size_t want = std::max(tile_bytes + tile_bytes / 4, (size_t)1 << 20);
-                    if (hipHostMalloc((void **)&ctx->h_stage, want, hipHostMallocDefault) == hipSuccess) ctx->h_stage_bytes = want;
-                    else ctx->h_stage = nullptr, (void)hipGetLastError();
+                    const hipError_t e = hipHostMalloc((void **)&ctx->h_stage, want, hipHostMallocDefault);
+                    if (e == hipSuccess) ctx->h_stage_bytes = want;
+                    else ctx->h_stage = nullptr, quiet(e);   // optional: the pageable route below takes over
                 }
                 tiles = ctx->h_stage;
             }
@@ -510,7 +526,8 @@ int32_t vtmc_extract_grid(vtmc_ctx *ctx, const float *grid, int32_t nx, int32_t 
                             for (int ix = 0; ix < 10; ++ix) t[ix + 10 * iy + 100 * iz] = org[ix * stride_x + iy * stride_y + iz * stride_z];
                 }
             }
-            return vtmc_extract_blocks(ctx, tiles, n_blocks, tri_count);   // blocking: the staging buffer is free again when it returns
+            // blocking: the staging buffer is free again when it returns -- also when it fails behind its upload (extract_blocks drains the stream then)
+            return vtmc_extract_blocks(ctx, tiles, n_blocks, tri_count);
         }
         if (int rc = upload_grid(ctx, grid, nx, ny, nz, stride_x, stride_y, stride_z)) return rc;
         if (int rc = ensure(ctx, ctx->list, sizeof(int32_t) * 3 * (size_t)std::max(n_blocks, 1))) return rc;
@@ -1049,10 +1066,7 @@ int32_t vtmc_density_fill_device_async(vtmc_ctx *ctx, const vtmc_density_params 
     const size_t org_bytes = sizeof(int32_t) * 3 * (size_t)n_volumes;
     if (ctx->origins_upload_pending) VTMC_HIP(ctx, hipEventSynchronize(ctx->ev_origins));   // the previous upload has left the staging words
     if (ctx->h_origins_bytes < org_bytes) {
-        if (ctx->h_origins) (void)hipHostFree(ctx->h_origins);
-    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-        ctx->h_origins = nullptr;
-        ctx->h_origins_bytes = 0;
+        release_pinned((void **)&ctx->h_origins, &ctx->h_origins_bytes);
         VTMC_HIP(ctx, hipHostMalloc((void **)&ctx->h_origins, org_bytes, hipHostMallocDefault));
         ctx->h_origins_bytes = org_bytes;
     }

@@ -83,6 +83,10 @@ struct vtmc_ctx {
     VtmcDevBuf comm_send;
     hipStream_t comm_stream = nullptr;   // the all-gather runs here, beside the emit kernel, when the counts leave the scan
     hipEvent_t ev_gather = nullptr;
+    hipEvent_t ev_last_gather = nullptr;   // behind the last all-gather this context queued, on the stream it went to
+    bool gather_recorded = false;
+    vtmc_ctx *comm_owner = nullptr;              // borrowed: whose communicator this is
+    std::vector<vtmc_ctx *> comm_borrowers;      // owned: the contexts that borrowed it (detached when the owner lets go)
     std::string err;
 };
 

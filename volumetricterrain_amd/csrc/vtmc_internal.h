@@ -88,7 +88,19 @@ constexpr int kQueueWords = 8 * 16 * 64;  // up to 16 ticket counters per XCD, 2
 constexpr uint32_t kCountMask = 0xFFFFu;  // counts[b]: triangles (<= 2560) | row mask << 16 (y layers 16-23, z layers 24-31)
 constexpr int kScanTile = 2048;  // block counts per scan workgroup (256 threads x 8)
 
-// Launch wrappers (mc_kernels.hip).  All asynchronous on `stream`; return hipGetLastError().
+// The runtime keeps ONE sticky "last error" word per thread: a failure nobody looked at stays there and is handed to whoever asks next.
+// Two rules keep a stale failure from being blamed on a launch (round 3's red suite was exactly that):
+//  * a launch wrapper clears the word before its launch and returns only what the launch left (launch_begin / launch_end);
+//  * a best-effort call whose failure is deliberately ignored (teardown, an optional pinned allocation) goes through quiet(), which
+//    consumes the sticky word together with the status.
+inline void launch_begin() { (void)hipGetLastError(); }
+inline hipError_t launch_end() { return hipGetLastError(); }
+inline void quiet(hipError_t e)
+{
+    if (e != hipSuccess) (void)hipGetLastError();
+}
+
+// Launch wrappers.  All asynchronous on `stream`; each returns the status of its own launch (launch_begin ... launch_end).
 // scan_ctrl / n_scan_ctrl: 64-bit words the kernel zeroes for the fused scan that follows (may be null / 0)
 hipError_t launch_classify_blocks(const BlockSpace &sp, const DeviceTables &tb, uint32_t *counts,
                                   uint8_t *cases_or_null, uint32_t *vcounts_or_null, int n_cus, unsigned long long *scan_ctrl,
