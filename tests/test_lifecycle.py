@@ -138,3 +138,41 @@ def test_a_stale_runtime_error_is_not_blamed_on_the_next_launch(oracle_mod):
         assert hip.hipFree(ctypes.c_void_p(0x1000)) != 0
         nd, T = ex.terrain_update([vt.PlaneModifier(4.5, (0, 0), (20, 20), True)])
         assert T == 2 * 16 * 16
+
+
+def test_the_owner_of_a_shared_communicator_goes_first(oracle_mod):
+    """vtmc_comm_share: when the OWNER lets go of the communicator first (vtmc_comm_destroy, or the garbage collector's order at
+    teardown), a collective the borrower queued on a caller's stream is waited for, the borrower is detached, and its next
+    all-gather is a clean VTMC_ERR_NO_RESULT -- never a call on a destroyed communicator."""
+    import torch
+    import volumetricterrain_amd as vt
+    c, dim, n_vol, per_rank = 32, 34, 3, 4
+    chunks = [oracle_mod.density_volume("perlin3d", c, origin=(c * i, 0, c)) for i in range(n_vol)]
+    d = torch.from_numpy(np.stack([np.ascontiguousarray(g.transpose(2, 1, 0)) for g in chunks])).cuda()
+    want = [oracle_mod.extract_grid(g, count_only=True)[0] for g in chunks]
+    owner, borrower = vt.Extractor(0), vt.Extractor(0)
+    try:
+        owner.comm_init_rank(owner.comm_unique_id(), 0, 1)
+        borrower.comm_share(owner)
+        side = torch.cuda.Stream()
+        gathered = torch.full((1, per_rank, 2), 0x7FFFFFFF, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        borrower.extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), n_vol, dim ** 3)
+        borrower.allgather_volume_counts(gathered.data_ptr(), per_rank, side.cuda_stream)   # on a stream only the caller knows
+        owner.comm_destroy()                     # waits for the borrower's collective, detaches the borrower
+        host = gathered.cpu().numpy().reshape(per_rank, 2)
+        assert list(host[:n_vol, 1]) == want     # the collective had finished before the communicator went
+        assert borrower.extract_finish() == sum(want)
+        with pytest.raises(vt.VtmcError) as err:
+            borrower.allgather_volume_counts(gathered.data_ptr(), per_rank)
+        assert err.value.code == -5
+        # both contexts still extract, and a new communicator can be made and shared again
+        assert owner.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), n_vol, dim ** 3) == sum(want)
+        owner.comm_init_rank(owner.comm_unique_id(), 0, 1)
+        borrower.comm_share(owner)
+        borrower.allgather_volume_counts(gathered.data_ptr(), per_rank)
+        host = borrower.copy_u32(gathered.data_ptr(), 2 * per_rank).reshape(per_rank, 2)
+        assert list(host[:n_vol, 1]) == want
+    finally:
+        owner.close()       # owner first, on purpose
+        borrower.close()
