@@ -254,7 +254,11 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
             const unsigned ny = ym | (ym << 1) | (ym << 2), nz = zm | (zm << 1) | (zm << 2);
             const bool zl = sp.zfast ? ((nz >> lq) & 1u) != 0u : true;
             const bool need0 = lane_ok && zl && ((ny >> rqc) & 1u), need1 = lane_ok && zl && ((ny >> (5 + rqc)) & 1u);
-            const unsigned o0 = need0 ? off0 : 0u, o1 = need1 ? off1 : 0u;
+            // a lane with nothing to fetch asks for a sample its block NEEDS anyway: the first one of the lowest needed row (ny x nz is an outer
+            // product, so that row is needed in every live slab).  Round 3 sent those lanes to the tile's first sample: row (y = 0, z = slab),
+            // not needed by four blocks in ten -- one extra 128-byte line per live slab of such a block (tools/_ab/line_fetch_exact.py).
+            const unsigned idle = ((sp.zfast ? (unsigned)__builtin_ctz(nz | 0x200u) * (unsigned)s_fast : 0u) + (unsigned)__builtin_ctz(ny | 0x200u) * (unsigned)sp.sy) * 4u;
+            const unsigned o0 = need0 ? off0 : idle, o1 = need1 ? off1 : idle;
             const unsigned live = sp.zfast ? 0x3FFu : nz;   // x-fastest: a z slab nobody needs is skipped (wave-uniform)
             const char *p = src;
 #define VTMC_ROW(C)                                  \
