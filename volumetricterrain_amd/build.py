@@ -76,5 +76,12 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(out, extra_flags):
+    """A diagnostic build next to the product library (e.g. tools/_ab/libvtmc_timeline.so with -DVTMC_TIMELINE); loaded through VTMC_LIB."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.run([hipcc] + FLAGS + list(extra_flags) + ["-ldl", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES], check=True)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

@@ -92,6 +92,10 @@ __global__ __launch_bounds__(256) void classify_blocks_kernel(BlockSpace sp, Dev
 // ----------------------------------------------------------------------------------------------
 // FROM_BITS: the signs come from the sampler's sign volume (SignVolume: tuning key "fill_keeps_signs") -- 2 x 8 bytes per row through the
 // scalar unit instead of 260 bytes per row through the vector memory path; the kernel is then instruction-bound.
+#ifdef VTMC_TIMELINE   // diagnostic build only (tools/classify_timeline.py): when every wave of the streaming classify started and ended, and where
+__device__ unsigned long long *g_vtmc_timeline = nullptr;   // [brick][4] = {start, end (s_memrealtime: 100 MHz), HW_ID, XCC_ID}
+#endif
+
 template <bool WANT_V, bool FROM_BITS>
 __global__ __launch_bounds__(256, WANT_V ? 3 : 1) void classify_dense_kernel(BlockSpace sp, DeviceTables tb,
                                                               uint32_t *__restrict__ counts,
@@ -101,6 +105,9 @@ __global__ __launch_bounds__(256, WANT_V ? 3 : 1) void classify_dense_kernel(Blo
 {
     __shared__ unsigned char s_trinum[256];
     const int lane = threadIdx.x & 63, wave = FROM_BITS ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : threadIdx.x >> 6;
+#ifdef VTMC_TIMELINE
+    const unsigned long long tl_start = __builtin_amdgcn_s_memrealtime();
+#endif
     // the fused scan that follows on the stream finds its ticket counter and tile status words zeroed
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n_scan_ctrl; i += gridDim.x * 256) scan_ctrl[i] = 0ull;
     {
@@ -172,6 +179,15 @@ __global__ __launch_bounds__(256, WANT_V ? 3 : 1) void classify_dense_kernel(Blo
         vc += __shfl_xor(vc, 4);
         if ((lane & 7) == 0 && in_volume) vcounts[bid] = vc;
     }
+#ifdef VTMC_TIMELINE
+    if (g_vtmc_timeline && lane == 0) {
+        unsigned long long *t = g_vtmc_timeline + 4ll * brick;
+        t[0] = tl_start;
+        t[1] = __builtin_amdgcn_s_memrealtime();
+        t[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        t[3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);    // HW_REG_XCC_ID
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -501,3 +517,10 @@ hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *off
 }
 
 }  // namespace vtmc
+
+#ifdef VTMC_TIMELINE
+extern "C" int32_t vtmc_debug_timeline(unsigned long long *d_buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(vtmc::g_vtmc_timeline), &d_buf, sizeof d_buf) == hipSuccess ? 0 : -4;
+}
+#endif
