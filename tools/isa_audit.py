@@ -20,13 +20,18 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "volumetricterrain_amd", "csrc", "emit_kernels.hip")
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only"]
+sys.path.insert(0, ROOT)
+from volumetricterrain_amd import build as vt_build  # noqa: E402
+
+# every translation unit with kernels that issue loads from inline asm, compiled with EXACTLY the product's flags (build.FLAGS minus the
+# link options): a flag the audit does not share could schedule, spill or merge differently from the library that ships
+SRCS = [os.path.join(vt_build.CSRC, f) for f in ("emit_kernels.hip", "onepass_kernels.hip")]
+FLAGS = [f for f in vt_build.FLAGS if f not in ("-shared", "-fPIC")] + ["-Wno-unused-command-line-argument", "-S", "--cuda-device-only"]
 
 
-def compile_asm(out):
+def compile_asm(out, src):
     hipcc = "/opt/rocm/bin/hipcc"
-    subprocess.run([hipcc] + FLAGS + ["-o", out, SRC], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([hipcc] + FLAGS + ["-o", out, src], check=True, stderr=subprocess.DEVNULL)
 
 
 def kernels(text):
@@ -91,7 +96,46 @@ def audit_kernel(name, lines):
     problems += sgpr_hazards(name, lines)
     if n_loads:
         problems += compiler_waits_in_loop(name, lines)
+        problems += counted_stores(name, lines)
     return (n_loads or None), problems
+
+
+def counted_stores(name, lines):
+    """The counted wait (wait_vm_at_most(vm_issued)) is right only while vm_issued never EXCEEDS the vector-memory instructions really issued
+    behind the tile loads.  The source adds one per store instruction it is sure of: a pass of stream_out_range (one 16-byte store per
+    lane: global_store_dwordx4, three unrolled passes), the two 12-byte vertex stores and the one 12-byte index store of the indexed
+    output (global_store_dwordx3).  A compiler that split, merged or narrowed one of them (two dwordx2 for a dwordx4, a dwordx4 for two
+    dwordx3 ...) would change the instruction count under the source's feet.  Checked here: in the main loop the record stores appear in
+    exactly the widths the source counts, in at least the multiplicity of one inlined copy, and nowhere as narrower pieces of them."""
+    head, in_asm, start = 0, False, 0   # the main loop starts at the last counted wait of the text (as compiler_waits_in_loop)
+    for i, l in enumerate(lines):
+        if "#ASMSTART" in l:
+            in_asm, start = True, i
+        elif "#ASMEND" in l:
+            in_asm = False
+        elif in_asm and "s_waitcnt vmcnt(48)" in l:
+            head = start
+    body = [l.split(";")[0].strip() for l in lines[head:]]
+    n4 = sum(1 for c in body if c.startswith("global_store_dwordx4"))
+    n3 = sum(1 for c in body if c.startswith("global_store_dwordx3"))
+    n2 = sum(1 for c in body if c.startswith("global_store_dwordx2"))
+    problems = []
+    indexed = False
+    if "emit_kernel" in name:
+        # template arguments in order: FAST, INDEXED, ASYNC, ONCE, WAVES
+        args = re.findall(r"Lb([01])E", name)
+        indexed = len(args) >= 2 and args[1] == "1"
+    if indexed:
+        if n3 < 3:
+            problems.append("%s: %d global_store_dwordx3 (the source counts 2 vertex stores + 1 index store per batch)" % (name[:60], n3))
+        if n4 or n2:
+            problems.append("%s: unexpected store widths in the indexed kernel (dwordx4 %d, dwordx2 %d)" % (name[:60], n4, n2))
+    else:
+        if n4 < 3 or n4 % 3:
+            problems.append("%s: %d global_store_dwordx4 (the source counts the three unrolled passes of stream_out_range per call)" % (name[:60], n4))
+        if n3 or n2:
+            problems.append("%s: unexpected store widths in the soup kernel (dwordx3 %d, dwordx2 %d)" % (name[:60], n3, n2))
+    return problems
 
 
 def compiler_waits_in_loop(name, lines):
@@ -166,10 +210,12 @@ def sgpr_hazards(name, lines):
 
 def main():
     keep = sys.argv[sys.argv.index("--keep") + 1] if "--keep" in sys.argv else None
+    text = ""
     with tempfile.TemporaryDirectory() as d:
-        path = keep or os.path.join(d, "emit.s")
-        compile_asm(path)
-        text = open(path).read()
+        for i, src in enumerate(SRCS):
+            path = (keep + (".%d" % i if i else "")) if keep else os.path.join(d, "unit%d.s" % i)
+            compile_asm(path, src)
+            text += open(path).read() + "\n"
     bad = []
     n_async = 0
     for name, lines in kernels(text).items():
