@@ -10,6 +10,26 @@ namespace vtmc {
 
 constexpr int kTriDwords = 19;     // 76-byte record
 
+// Diagnostic build -DVTMC_EMIT_TIMING (tools/emit_phases.py): shader cycles a wave spends in each phase of a block, summed over all waves.
+// In the product build the clock is an empty object and every mark compiles to nothing.
+#ifdef VTMC_EMIT_TIMING
+struct PhaseClock {
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
+    __device__ __forceinline__ void start() { last = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void mark(int i)
+    {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        acc[i] += now - last;
+        last = now;
+    }
+};
+#else
+struct PhaseClock {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+};
+#endif
+
 // ----------------------------------------------------------------------------------------------
 // Per-block emit:
 //   * pass 1 classifies (8 unrolled layers) and compacts the ACTIVE cells with one ballot per layer;
@@ -425,7 +445,7 @@ __device__ __forceinline__ void eval_vertex(const float *tile, unsigned d, float
 
 template <bool FAST>
 __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_vert, const OnceTables *tb, size_t tri_base, int budget,
-                                                int block_id, float *__restrict__ out, int lane, int ablate, unsigned rowmask, int &vm_issued)
+                                                int block_id, float *__restrict__ out, int lane, int ablate, unsigned rowmask, int &vm_issued, PhaseClock &pc)
 {
     if (budget > kSlotCap) {   // wave-uniform: more triangles than the slot buffer holds -- the per-corner path with its own flushes
         emit_block_from_tile<FAST>(&L->c, s_vert, tri_base, budget, block_id, out, lane, ablate, rowmask, vm_issued);
@@ -434,6 +454,7 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
     const float *tile = L->c.tile;
     const int n_act = compact_active_cells(tile, L->c.acell, lane, rowmask);   // pass 1
     VTMC_WAVE_SYNC();
+    pc.mark(2);
     unsigned short *vlist = L->vlist();
     unsigned char *vtab = L->vtab();
 
@@ -491,6 +512,7 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
         return;
     }
     VTMC_WAVE_SYNC();
+    pc.mark(3);
 
     // V: one lane per vertex, from the edge's low endpoint
     float *verts = L->verts();
@@ -505,6 +527,7 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
         }
     }
     VTMC_WAVE_SYNC();
+    pc.mark(4);
 
     // T: one lane per triangle; the staging area lies over the tile, which nobody reads any more
     float *stage = L->c.tile;
@@ -533,7 +556,9 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
             }
         }
         const int cnt = pending - s0 < 64 ? pending - s0 : 64;
+        pc.mark(5);
         stream_batch76(stage, rec, s < pending, cnt, (tri_base + (size_t)s0) * kTriDwords, block_id, out, lane, ablate, vm_issued);
+        pc.mark(6);
     }
 }
 

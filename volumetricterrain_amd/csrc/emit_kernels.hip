@@ -9,6 +9,10 @@
 
 namespace vtmc {
 
+#ifdef VTMC_EMIT_TIMING
+__device__ unsigned long long *g_vtmc_emit_phases = nullptr;   // [8] shader cycles per phase + [8] = blocks, summed over all waves
+#endif
+
 // ----------------------------------------------------------------------------------------------
 // Loads hipcc does not count.  gfx950 keeps ONE counter (vmcnt) for vector loads, stores and returning
 // atomics, retired in issue order.  A wave that prefetches its next tile, emits a data-dependent number
@@ -298,6 +302,8 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
         };
         auto collect_async = [&]() { return queue ? ai_begin + (int)__builtin_amdgcn_readfirstlane(tick) : tick_static; };
         int vm_issued = 0;
+        PhaseClock pc;
+        unsigned long long n_blocks_done = 0;
         request_async();
         wait_vm_at_most(0, pre, tick);
         Blk cur = describe(collect_async());
@@ -306,9 +312,12 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
         Blk nxt = describe(collect_async());
         if (cur.b >= 0) load_rows_async(reinterpret_cast<const char *>(sp.base + block_origin(sp, cur.b)), cur.mask, pre);
         request_async();
+        pc.start();
         while (cur.b >= 0) {
             wait_vm_at_most(vm_issued, pre, tick);   // tile `cur` and the ticket of the block after `nxt` have landed; younger stores stay in flight
             vm_issued = 0;
+            pc.mark(0);
+            ++n_blocks_done;
             VTMC_WAVE_SYNC();
             store_tile(tile_of(L), pre);
             const int far_entry = collect_async();
@@ -316,22 +325,31 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
             request_async();
             const Blk far = describe(far_entry);   // two dependent scalar loads: behind the tile loads, so only the wave's own LDS work waits for them
             VTMC_WAVE_SYNC();
+            pc.mark(1);
             const int budget = (int)(cur.tri_end - cur.tri_base);
             if constexpr (INDEXED)
                 emit_block_indexed<FAST>(L, s_vert, s_own, &s_once[0], (size_t)cur.tri_base, budget, (size_t)cur.vert_base, (int)(cur.vert_end - cur.vert_base), out,
                                          out_indices, lane, ablate, cur.mask, vm_issued);
             else if constexpr (ONCE)
-                emit_block_once<FAST>(L, s_vert, &s_once[0], (size_t)cur.tri_base, budget, cur.b, out, lane, ablate, cur.mask, vm_issued);
+                emit_block_once<FAST>(L, s_vert, &s_once[0], (size_t)cur.tri_base, budget, cur.b, out, lane, ablate, cur.mask, vm_issued, pc);
             else
                 emit_block_from_tile<FAST>(L, s_vert, (size_t)cur.tri_base, budget, cur.b, out, lane, ablate, cur.mask, vm_issued);
             cur = nxt;
             nxt = far;
+            pc.mark(7);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last ticket (nobody reads it) has landed before the wave ends
+#ifdef VTMC_EMIT_TIMING
+        if (g_vtmc_emit_phases && lane == 0) {
+            for (int i = 0; i < 8; ++i) atomicAdd(g_vtmc_emit_phases + i, pc.acc[i]);
+            atomicAdd(g_vtmc_emit_phases + 8, n_blocks_done);
+        }
+#endif
     } else {
     int b_next = 0;
     unsigned mask_next = 0xFFFFu;
     int vm_unused = 0;
+    PhaseClock pc_unused;
     request();
     int ai = collect();
     request();
@@ -360,7 +378,7 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
             emit_block_indexed<FAST>(L, s_vert, s_own, &s_once[0], tri_base, budget, (size_t)voffsets[b], (int)(voffsets[b + 1] - voffsets[b]), out,
                                      out_indices, lane, ablate, mask, vm_unused);
         else if constexpr (ONCE)
-            emit_block_once<FAST>(L, s_vert, &s_once[0], tri_base, budget, b, out, lane, ablate, mask, vm_unused);
+            emit_block_once<FAST>(L, s_vert, &s_once[0], tri_base, budget, b, out, lane, ablate, mask, vm_unused, pc_unused);
         else
             emit_block_from_tile<FAST>(L, s_vert, tri_base, budget, b, out, lane, ablate, mask, vm_unused);
         ai = ai_next;
@@ -431,3 +449,10 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
 }
 
 }  // namespace vtmc
+
+#ifdef VTMC_EMIT_TIMING
+extern "C" int32_t vtmc_debug_emit_phases(unsigned long long *d_buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(vtmc::g_vtmc_emit_phases), &d_buf, sizeof d_buf) == hipSuccess ? 0 : -4;
+}
+#endif

@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256, 3) void onepass_kernel(BlockSpace sp, DeviceTa
     };
 
     int vm_unused = 0;
+    PhaseClock pc_unused;
     bool more = true;   // tickets left
     // prefix (the groups before + the bricks before it in its group), offsets, emission
     auto finish = [&](const Entry &e) {
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256, 3) void onepass_kernel(BlockSpace sp, DeviceTa
             VTMC_T(4);   // tile
             if (tri_base + (unsigned long long)budget > (unsigned long long)capacity) continue;   // the host grows the buffer and runs the step again
             const int bid = at.bid0 + at.segx * 8 + (l8 >> 3);
-            if constexpr (FAST) emit_block_once<true>(L, s_vert, &s_once[0], (size_t)tri_base, budget, bid, out, lane, ablate, rmask, vm_unused);
+            if constexpr (FAST) emit_block_once<true>(L, s_vert, &s_once[0], (size_t)tri_base, budget, bid, out, lane, ablate, rmask, vm_unused, pc_unused);
             else emit_block_from_tile<false>(L, s_vert, (size_t)tri_base, budget, bid, out, lane, ablate, rmask, vm_unused);
             VTMC_T(5);   // emission
         }
