@@ -245,6 +245,20 @@ __global__ __launch_bounds__(256) void write_plain_kernel(v4f *__restrict__ dst,
     if (i < n) dst[i] = (v4f){1.f, 2.f, 3.f, (float)threadIdx.x};
 }
 
+// How much does the NUMBER OF CONCURRENT FRONTS cost a read stream?  Workgroup b reads the 4-KiB piece (b % F) * (n_wgs / F) + b / F: F = 1 is the
+// plain kernel (one front sweeping the buffer), F = 8 what "every XCD streams its own contiguous eighth" does, larger F what a brick order
+// does that keeps ~100 sample planes open per XCD (classify_dense_kernel).  PIECE float4 per thread (1: 4 KiB per workgroup, the plain kernel).
+__global__ __launch_bounds__(256) void read_fronts_kernel(const v4f *__restrict__ src, v4f *__restrict__ sink, long long n_wgs, int fronts)
+{
+    const long long b = blockIdx.x;
+    const long long per = n_wgs / fronts;
+    const long long piece = (b % fronts) * per + b / fronts;
+    if (b / fronts < per) {
+        const v4f v = src[piece * 256 + threadIdx.x];
+        if (v.x == 1.2345e30f) sink[0] = v;
+    }
+}
+
 // Time-division of the two directions (round 4 experiment): the mixes above lose 10-25 % against the weighted read-only / write-only rates.
 // Is that the memory's read <-> write turn-around?  Here every wave issues its loads only inside the "read window" of a chip-wide clock
 // (s_memrealtime, 100 MHz: the first `read_ticks` of every `period_ticks`) and its stores only outside it -- no communication, every wave
@@ -376,6 +390,30 @@ int main(int argc, char **argv)
                        bytes / 1e9, ms[reps / 2], bytes / ms[reps / 2] / 1e9, bytes / ms[0] / 1e9);
                 fflush(stdout);
             }
+        }
+        CK(hipFree(buf));
+        return 0;
+    }
+
+    if (argc > 2 && !strcmp(argv[2], "fronts")) {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        const long long n_wgs = total_f4 / 256;
+        for (int fronts : {1, 8, 16, 64, 128, 512, 1024, 4096, 32768}) {
+            std::vector<float> ms(reps);
+            for (int i = 0; i < reps + 1; ++i) {
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(read_fronts_kernel, dim3((unsigned)n_wgs), dim3(256), 0, 0, buf, buf, n_wgs, fronts);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                if (i) CK(hipEventElapsedTime(&ms[i - 1], e0, e1));
+            }
+            std::sort(ms.begin(), ms.end());
+            const double bytes = (double)(n_wgs / fronts) * fronts * 4096.0;
+            printf("{\"kernel\": \"read_fronts\", \"fronts\": %d, \"GB\": %.3f, \"ms_med\": %.4f, \"TBps_med\": %.3f, \"TBps_best\": %.3f}\n", fronts, bytes / 1e9,
+                   ms[reps / 2], bytes / ms[reps / 2] / 1e9, bytes / ms[0] / 1e9);
+            fflush(stdout);
         }
         CK(hipFree(buf));
         return 0;

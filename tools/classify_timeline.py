@@ -24,7 +24,12 @@ ex = vt.Extractor(0)
 org_all = sharding.chunk_origins(n, c)
 d = torch.empty(len(org_all) * dim ** 3, dtype=torch.float32, device="cuda")
 ex.density_fill_device(vt.density_params("perlin3d", n), org_all, (dim, dim, dim), (1, dim, dim * dim), dim ** 3, d.data_ptr())
-for n_chunks in [int(a) for a in sys.argv[1:]] or [512, 64]:
+tuning = [a for a in sys.argv[1:] if "=" in a]   # e.g. emit_ablate=1: the emit kernel of the step before leaves no dirty lines behind
+for item in tuning:
+    k, v = item.split("=")
+    ex.set_tuning(**{k: int(v)})
+    print("tuning: %s" % item)
+for n_chunks in [int(a) for a in sys.argv[1:] if "=" not in a] or [512, 64]:
     n_bricks = n_chunks * 16 * 16 * 2
     buf = torch.zeros(n_bricks * 4, dtype=torch.int64, device="cuda")
     assert L.vtmc_debug_timeline(buf.data_ptr()) == 0
