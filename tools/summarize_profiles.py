@@ -104,9 +104,28 @@ def main():
             shutil.copy(os.path.join(src, "calib", "chunks.jsonl"), os.path.join(dst, "mix2_chunked_writes.jsonl"))
         calib = {"best_median_TBps_by_mix": best,
                  "note": "tools/calib/mix2: persistent grids of 1-8 workgroups per CU, 1-8 float4 in flight per lane, plain and non-temporal stores; the best median of every read : write mix"}
+        # round 4: the plainest kernels there are (one float4 per thread, the grid as large as the buffer) -- they beat every persistent shape
+        plain_f = os.path.join(src, "calib", "plain.jsonl")
+        if os.path.exists(plain_f):
+            shutil.copy(plain_f, os.path.join(dst, "mix2_plain_kernels.jsonl"))
+            plain = collections.OrderedDict()
+            for r in (json.loads(ln) for ln in open(plain_f) if ln.startswith("{")):
+                if r["GiB_total"] >= 2.0:   # beyond the 256 MB Infinity Cache
+                    plain[r["kernel"]] = max(plain.get(r["kernel"], 0.0), r["TBps_med"])
+            calib["plain_kernels_TBps"] = plain
+            calib["note_plain"] = ("tools/calib/mix2 <GiB> copy: one float4 per thread, non-persistent (copy_plain_4 / _8: that many float4 a grid-stride apart), "
+                                   "hipMemcpy device to device; best median over buffers of 2 GiB and more")
+        fronts_f = os.path.join(src, "calib", "fronts.jsonl")
+        if os.path.exists(fronts_f):
+            shutil.copy(fronts_f, os.path.join(dst, "mix2_read_fronts.jsonl"))
+            calib["read_TBps_by_concurrent_fronts"] = collections.OrderedDict(
+                (str(r["fronts"]), r["TBps_med"]) for r in (json.loads(ln) for ln in open(fronts_f) if ln.startswith("{")))
         json.dump(calib, open(os.path.join(dst, "memory_ceilings.json"), "w"), indent=1)
     except Exception as e:   # noqa: BLE001
         print("no calibration:", e)
+    for name in ("pytest_gpu.log", "emit_phases.txt", "classify_timeline.txt", "dropin_route.txt"):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, name))
     for name in ("ab_emit_variants.txt", "ab_emit_ablation.txt"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, name))
