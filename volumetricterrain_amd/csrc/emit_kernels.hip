@@ -303,7 +303,7 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
         auto collect_async = [&]() { return queue ? ai_begin + (int)__builtin_amdgcn_readfirstlane(tick) : tick_static; };
         int vm_issued = 0;
         PhaseClock pc;
-        unsigned long long n_blocks_done = 0;
+        [[maybe_unused]] unsigned long long n_blocks_done = 0;
         request_async();
         wait_vm_at_most(0, pre, tick);
         Blk cur = describe(collect_async());
