@@ -161,17 +161,19 @@ int32_t vtmc_reserve_triangles(vtmc_ctx *ctx, int64_t capacity);
  * The reference's only timing hook is the commented-out timer at VoxelTerrain.cs:363/467. */
 int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4]);
 
-/* Selects a kernel variant / launch shape, mainly for A/B measurements in one process.  Keys that
- * keep results within the parity bar: "emit_fast_math" (1: v_rcp / v_rsq / fma, default; 0: correctly
- * rounded, bit-compatible with the CPU oracle), "emit_wgs_per_cu", "emit_dynamic",
- * "emit_sub_log2", "emit_group_log2", "gather_beside" (default 0: the all-gather of a queued extract runs behind the emit kernel on
- * the caller's stream; 1: beside it on the context's second stream), "emit_async" (default 1: tile prefetch and tickets outside the
- * compiler's vmcnt bookkeeping; 0: round 2's loop), "emit_once" (default 1: with emit_fast_math, every welded vertex of a block is
- * evaluated once and the 76-byte records are expanded from LDS; 0: per triangle corner), "one_pass" (default 0; 1: a dense x-fastest
- * soup batch is classified, scanned and emitted in ONE launch -- same bytes, measured slower: DESIGN.md section 4; "one_pass_unit":
- * its look-back groups per work unit), "emit_idx_waves" (indexed output: 4, default: four emit workgroups of four waves per CU; 3: six of
- * three = 18 waves, measured no faster).  "emit_ablate" / "classify_ablate" switch parts
- * of a kernel off for diagnosis and make the output INVALID.  Defaults are the shipped configuration.
+/* Selects a kernel variant / launch shape, mainly for A/B measurements in one process.  Every key and value the library accepts keeps
+ * results within the parity bar and is compared with the CPU oracle by tests/test_tuning_matrix.py; an unknown key or a value outside
+ * a key's range answers VTMC_ERR_INVALID_ARG and changes nothing.  Keys: "emit_fast_math" (1: v_rcp / v_rsq / fma, default; 0: correctly
+ * rounded, bit-compatible with the CPU oracle), "emit_once" (default 1: with emit_fast_math, every welded vertex of a block is evaluated
+ * once and the 76-byte records are expanded from LDS; 0: per triangle corner), "emit_dynamic" (default 1: per-XCD ticket counters; 0: a
+ * static round-robin over the list of non-empty blocks), "emit_sub_log2" (0-4, default 1: 2^s ticket counters per XCD),
+ * "emit_row_masks" (default 1: only tile rows next to cells with triangles are fetched), "emit_wgs_per_cu" (0-8; 0, default: the
+ * kernel's own residency), "emit_idx_waves" (indexed output: 4, default: four emit workgroups of four waves per CU; 3: six of three),
+ * "classify_wgs_per_cu" (0-7, default 3: residency cap of the streaming classify kernel; 0: none), "density_wgs_per_cu" (0-8; residency
+ * cap of the synthetic sampler), "stage_events" (default 1: HIP events between the three kernels for vtmc_last_stage_ms; 0: only around
+ * the step), "gather_beside" (default 0: the all-gather of a queued extract runs behind the emit kernel on the caller's stream; 1: beside
+ * it on the context's second stream).  The diagnostic keys "emit_ablate" / "classify_ablate" / "density_ablate" (parts of a kernel
+ * switched off, output INVALID) exist only in -DVTMC_DIAGNOSTICS builds of the library (tools/build_diagnostics.py).
  * "fill_keeps_signs" (default 0) is a contract, not a variant: with 1, vtmc_density_fill_device[_async] also leaves
  * one sign bit per sample in context memory, and an extract by the SAME context of exactly that buffer (pointer,
  * dims, strides, volume count) classifies from those bits instead of the samples (1/32 of the bytes; results are

@@ -16,7 +16,7 @@ def pytest_configure(config):
 # Collection order of the GPU suite.  The driver runs `pytest -m gpu -x`: whatever comes after the first failure is never
 # reached, so the rows of SURVEY.md section 8 come first (goldens -> core parity -> the lifecycle sequence -> configs[1] / [2] ->
 # indexed output -> terrain -> chunk files -> config 5) and the auxiliary surfaces last (sampler twin, sign-bit classify,
-# one-pass, bench modes, the RCCL world-of-one).  First matching pattern wins; unmatched tests go to the end, in file order.
+# the tuning matrix, bench modes, the RCCL world-of-one).  First matching pattern wins; unmatched tests go to the end, in file order.
 GPU_ORDER = [
     r"test_golden\.py",
     r"test_gpu_parity\.py::test_exact_mode",
@@ -40,14 +40,13 @@ GPU_ORDER = [
     r"test_terrain\.py",
     r"test_host_mirror\.py",
     r"test_gpu_parity\.py::test_chunk_file",
-    r"test_chunkfile\.py",
     r"test_gpu_parity\.py::test_sharded_host_entry",
     r"test_gpu_parity\.py::test_streaming_shards",
     r"test_gpu_parity\.py::test_config_streaming",
     r"test_config5_full\.py",
     r"test_gpu_parity\.py::test_density_sampler",
     r"test_gpu_parity\.py::test_classify_from_the_samplers",
-    r"test_gpu_parity\.py::test_one_pass",
+    r"test_tuning_matrix\.py",
     r"test_gpu_parity\.py::test_rccl",
     r"test_bench_modes\.py",
 ]

@@ -154,43 +154,6 @@ def test_queued_extract_regrows_and_equals_blocking(ex, oracle_mod):
         ex.set_tuning(stage_events=1)
 
 
-def test_one_pass_matches_three_launches(ex, oracle_mod):
-    """tuning key one_pass (opt-in: onepass_kernels.hip): classify + chained scan + emit in ONE launch give the bytes, the per-block
-    offsets and the per-volume counts of the three-launch step -- device batches and host grids with partial 64-lane segments, both
-    arithmetic modes, a buffer that has to grow, and against the oracle."""
-    import torch
-    c, dim = 64, 66
-    chunks = [oracle_mod.density_volume("perlin3d", c, origin=(64 * i, 0, 64)) for i in range(5)]
-    d = torch.from_numpy(np.stack([np.ascontiguousarray(g.transpose(2, 1, 0)) for g in chunks])).cuda()
-    counts = torch.zeros((5, 2), dtype=torch.int32, device="cuda")
-    try:
-        for fast in (1, 0):
-            ex.set_tuning(one_pass=0, emit_fast_math=fast)
-            T0 = ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 5, dim ** 3)
-            want, want_offs = ex.read_triangles()
-            ex.set_tuning(one_pass=1)
-            ex.reserve_triangles(1)      # too small: the kernel writes nothing past it, finish() grows the buffer and runs the step again
-            ex.extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 5, dim ** 3)
-            assert ex.extract_finish() == T0
-            ex.copy_volume_counts_device(counts.data_ptr(), 5)
-            got, offs = ex.read_triangles()
-            assert got.tobytes() == want.tobytes() and np.array_equal(offs, want_offs)
-            torch.cuda.synchronize()
-            vc = counts.cpu().numpy()
-            assert vc[:, 1].sum() == T0 and np.array_equal(vc[:, 0], 3 * vc[:, 1])
-            ms = ex.last_stage_ms()
-            assert ms["total"] > 0 and ms["emit"] > 0
-        for n in ((40, 16, 24), (136, 8, 8), (200, 24, 8), (264, 40, 24), (64, 64, 64)):     # exact mode (set above) against the oracle, bit for bit; 264 x 40 x 24: 75 bricks = one look-back group + a partial one
-            g = fields.random_field(n, seed=n[0])
-            want, want_offs, _ = oracle_mod.extract_grid(g, threads=8)
-            assert ex.extract_grid(g) == len(want)
-            got, offs = ex.read_triangles()
-            assert np.array_equal(offs, want_offs)
-            assert_tris_match(got, want, atol=0)
-    finally:
-        ex.set_tuning(one_pass=0, emit_fast_math=1)
-
-
 @pytest.mark.parametrize("dims,n_vol,kind,indexed", [((128, 128, 128), 3, "fbm8", False), ((96, 40, 24), 2, "perlin3d", False),
                                                     ((200, 16, 8), 3, "fbm8", True), ((64, 64, 64), 1, "perlin3d", True)])
 def test_classify_from_the_samplers_sign_bits(ex, oracle_mod, dims, n_vol, kind, indexed):

@@ -25,7 +25,7 @@ from volumetricterrain_amd import build as vt_build  # noqa: E402
 
 # every translation unit with kernels that issue loads from inline asm, compiled with EXACTLY the product's flags (build.FLAGS minus the
 # link options): a flag the audit does not share could schedule, spill or merge differently from the library that ships
-SRCS = [os.path.join(vt_build.CSRC, f) for f in ("emit_kernels.hip", "onepass_kernels.hip")]
+SRCS = [os.path.join(vt_build.CSRC, f) for f in ("emit_kernels.hip",)]
 FLAGS = [f for f in vt_build.FLAGS if f not in ("-shared", "-fPIC")] + ["-Wno-unused-command-line-argument", "-S", "--cuda-device-only"]
 
 

@@ -14,7 +14,7 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvtmc.so")
-SOURCES = ["vtmc_api.hip", "classify_kernels.hip", "emit_kernels.hip", "onepass_kernels.hip", "terrain.hip", "density.hip",
+SOURCES = ["vtmc_api.hip", "classify_kernels.hip", "emit_kernels.hip", "terrain.hip", "density.hip",
            "chunk_io.hip", "comm.hip"]
 HEADERS = ["vtmc_internal.h", "vtmc_ctx.h", "mc_device.h", "emit_device.h", "mc_tables_packed.h", os.path.join("..", "..", "include", "vtmc.h")]
 # -fno-slp-vectorize: hipcc's SLP pass packs adjacent FP32 operations into v_pk_fma_f32 / v_pk_add_f32 (+ moves to
@@ -24,8 +24,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared"
          "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
 
 
-# the device code of the DEFAULT extract path and the tuning defaults that select its variants (host-side files do not change a kernel's
-# traffic; onepass_kernels.hip is an opt-in the committed counters were not taken on)
+# the device code of the extract path and the tuning defaults that select its variants (host-side files do not change a kernel's traffic)
 EXTRACT_KERNEL_FILES = ["classify_kernels.hip", "emit_kernels.hip", "emit_device.h", "mc_device.h", "mc_tables_packed.h", "vtmc_internal.h"]
 
 

@@ -100,10 +100,11 @@ template <bool WANT_V, bool FROM_BITS>
 __global__ __launch_bounds__(256, WANT_V ? 3 : 1) void classify_dense_kernel(BlockSpace sp, DeviceTables tb,
                                                               uint32_t *__restrict__ counts,
                                                               uint32_t *__restrict__ vcounts,
-                                                              int nsegx, int n_bricks, int n_wgs, int ablate,
+                                                              int nsegx, int n_bricks, int n_wgs, int ablate_arg,
                                                               unsigned long long *__restrict__ scan_ctrl, int n_scan_ctrl, SignVolume sg, int lane_is_z)
 {
     __shared__ unsigned char s_trinum[256];
+    const int ablate = VTMC_ABLATE(ablate_arg);
     const int lane = threadIdx.x & 63, wave = FROM_BITS ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : threadIdx.x >> 6;
 #ifdef VTMC_TIMELINE
     const unsigned long long tl_start = __builtin_amdgcn_s_memrealtime();

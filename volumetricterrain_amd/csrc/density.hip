@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
         for (int pass = 0; pass < kLanesPerCol; ++pass) {
             const int c = tid / kLanesPerCol + (256 / kLanesPerCol) * pass, q4 = 4 * (tid % kLanesPerCol);
             const long long base = s_col[c];
-            if (base >= 0 && q4 < n && !(dl.ablate & 1)) {
+            if (base >= 0 && q4 < n && !(VTMC_ABLATE(dl.ablate) & 1)) {
                 float *p = out + base + first + q4;   // sz == 1
                 if (q4 + 4 <= n) {
                     *reinterpret_cast<v4u *>(p) = v4u{s_tr[q4][c], s_tr[q4 + 1][c], s_tr[q4 + 2][c], s_tr[q4 + 3][c]};
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
             s_tr[jj % kTrSteps][tid] = value;
             if (jj % kTrSteps == kTrSteps - 1 || jj == w_count - 1) flush_transposed(jj - jj % kTrSteps, jj % kTrSteps + 1);   // workgroup-uniform
         } else {
-            if (live && (!(dl.ablate & 1) || sum == 1e30f)) *dst = value;   // ablate 1: diagnostics, no stores
+            if (live && (!(VTMC_ABLATE(dl.ablate) & 1) || sum == 1e30f)) *dst = value;   // ablate 1: diagnostics, no stores
             dst += dst_step;
         }
         if (signs) {   // the sign volume (z walk only): one ballot per wave and step -- what the classify stage needs of this sample

@@ -110,25 +110,26 @@ __device__ __forceinline__ void wait_vm_at_most(int n, float (&t)[20], unsigned 
 // ----------------------------------------------------------------------------------------------
 //   INDEXED: welded vertices + block-local indices (emit_block_indexed) instead of 76-byte records;
 //   `out` then is the vertex buffer, voffsets / vcapacity / out_indices its extra operands.
-//   ASYNC: the next tile and the next ticket travel outside the compiler's vmcnt bookkeeping (gload_async above) and a block's
-//   stores are never waited for; !ASYNC is round 2's loop (kept for same-box A/Bs: tuning key "emit_async").
+//   The next tile and the next ticket travel outside the compiler's vmcnt bookkeeping (gload_async above) and a block's stores are never
+//   waited for (round 2's synchronous loop: profiles/r05/experiments/onepass_and_sync_loop.patch).
 //   ONCE (soup only): every welded vertex of a block is evaluated one time into LDS and the records are expanded from there
 //   (emit_block_once, emit_device.h); 53 KB of LDS per workgroup: three workgroups per CU.
 //   WAVES: waves per workgroup.  The indexed output's per-wave LDS is small enough that the shared tables decide how many waves fit a CU:
 //   three-wave workgroups, six per CU = 18 waves (four-wave workgroups: 16); the kernel is latency-bound there (0.92 / 0.68 / 0.59 ms at
 //   8 / 12 / 16 waves).  Workgroups of more than 256 threads get fewer slots than their LDS would allow (measured, tools/_ab/occ2.hip:
 //   52 KB x 384 threads: two per CU where the occupancy query says three).
-template <bool FAST, bool INDEXED, bool ASYNC, bool ONCE = false, int WAVES = kWavesPerWg>
+template <bool FAST, bool INDEXED, bool ONCE = false, int WAVES = kWavesPerWg>
 __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void emit_kernel(BlockSpace sp, DeviceTables tb,
                                                     const uint32_t *__restrict__ offsets,
                                                     const int32_t *__restrict__ active_list,
                                                     const uint32_t *__restrict__ totals, uint32_t capacity,
-                                                    float *__restrict__ out, int group_log2, int ablate, unsigned *__restrict__ queue, int sub_log2,
+                                                    float *__restrict__ out, int ablate_arg, unsigned *__restrict__ queue, int sub_log2,
                                                     const uint32_t *__restrict__ voffsets, const uint32_t *__restrict__ vtotals,
                                                     uint32_t vcapacity, int *__restrict__ out_indices,
                                                     const uint32_t *__restrict__ rowmasks, uint32_t *__restrict__ volume_counts, int n_volumes)
 {
     static_assert(!(ONCE && INDEXED), "ONCE is a form of the soup");
+    const int ablate = VTMC_ABLATE(ablate_arg);   // product build: 0, every diagnostic branch below folds away
     using Lds = typename std::conditional<INDEXED, EmitLdsIdx, typename std::conditional<ONCE, EmitLdsOnce, EmitLds2>::type>::type;
     __shared__ Lds s_lds[WAVES];
     __shared__ u64 s_vert[256];
@@ -187,26 +188,6 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
     // Row masks from the classify pass (upper half of the block's count word): a tile row (y, z) is only fetched when a cell with triangles
     // can touch it (its layer or one of the two below, on both axes) -- about 64 % of the rows on the
     // benchmark field.  Rows not fetched keep stale values; pass 1 skips their cells.
-    auto load_rows = [&](const char *src, unsigned mask, float (&dst)[20]) {
-        const unsigned ym = mask & 0xFFu, zm = mask >> 8;
-        const unsigned ny = ym | (ym << 1) | (ym << 2), nz = zm | (zm << 1) | (zm << 2);
-        const bool zl = sp.zfast ? ((nz >> lq) & 1u) != 0u : true;   // z-fastest: the lane's own z row
-        const bool need0 = lane_ok && zl && ((ny >> rqc) & 1u), need1 = lane_ok && zl && ((ny >> (5 + rqc)) & 1u);
-        // the two row groups under ONE exec mask each (a lane's need is the same for all ten slabs), slab pointer
-        // advanced by addition: the scalar unit sees two mask set-ups and ten adds per tile, not twenty of each
-        if (need0) {
-            const char *p = src + off0;
-#pragma unroll
-            for (int c = 0; c < 10; ++c, p += slab_bytes)
-                if ((sp.zfast || ((nz >> c) & 1u)) && (!(ablate & 8) || c < 6)) dst[2 * c] = *reinterpret_cast<const float *>(p);   // x-fastest: a z slab nobody needs is skipped (wave-uniform); ablate 8: diagnostics
-        }
-        if (need1) {
-            const char *p = src + off1;
-#pragma unroll
-            for (int c = 0; c < 10; ++c, p += slab_bytes)
-                if ((sp.zfast || ((nz >> c) & 1u)) && (!(ablate & 8) || c < 6)) dst[2 * c + 1] = *reinterpret_cast<const float *>(p);
-        }
-    };
     auto store_tile = [&](float *tile, const float (&v)[20]) {
         if (lane_ok) {
 #pragma unroll
@@ -226,31 +207,17 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
     const int part = xcd * n_sub + (queue ? (j & (n_sub - 1)) : 0), n_part = 8 * n_sub;
     const int ai_begin = (int)((long long)n_active * part / n_part);
     const int ai_end = (int)((long long)n_active * (part + 1) / n_part);
-    // the k-th block of this wave: rounds of (waves per XCD) groups, each wave takes 2^group_log2
-    // consecutive list entries per round (x-adjacent blocks share 128-byte lines)
+    // static distribution: the k-th block of this wave, round-robin over the waves of the XCD
     const int u = j * WAVES + wave, n_u = per_xcd * WAVES;
-    auto entry = [&](int k) {
-        const int r = k >> group_log2, g = k & ((1 << group_log2) - 1);
-        return ai_begin + (((r * n_u + u) << group_log2) | g);
-    };
+    auto entry = [&](int k) { return ai_begin + k * n_u + u; };
 
     // Work distribution.  Static: entry(k).  Dynamic (queue != nullptr): one ticket counter per XCD,
     // so the blocks in flight on an XCD are always the next ones in list order -- spatial neighbours
     // (shared halo rows / 128-byte lines) stay within the few microseconds a line survives in L2.
     // The ticket for block k+2 is requested while block k is processed, its tile one block ahead.
     int k_static = 0;
-    unsigned tick_raw = 0;  // lane 0 holds the ticket the last request returned
-    auto request = [&]() {
-        if (queue) {
-            if (lane == 0) tick_raw = __hip_atomic_fetch_add(queue + part * 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            tick_raw = (unsigned)(entry(k_static++) - ai_begin);
-        }
-    };
-    auto collect = [&]() { return ai_begin + (int)__builtin_amdgcn_readfirstlane(tick_raw); };
-
     float pre[20] = {};  // rows a block does not need keep whatever an earlier block left: never used
-    if constexpr (ASYNC) {
+    {
         // the same two row groups, issued from inline asm: the compiler neither counts nor waits for them.  A lane that needs no
         // row reads the tile's first sample instead (one address for all of them: a broadcast hit), a slab nobody needs is skipped.
         auto load_rows_async = [&](const char *src, unsigned mask, float (&dst)[20]) {
@@ -345,45 +312,6 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
             atomicAdd(g_vtmc_emit_phases + 8, n_blocks_done);
         }
 #endif
-    } else {
-    int b_next = 0;
-    unsigned mask_next = 0xFFFFu;
-    int vm_unused = 0;
-    PhaseClock pc_unused;
-    request();
-    int ai = collect();
-    request();
-    int ai_next = collect();
-    if (ai < ai_end) {
-        b_next = active_list[ai];
-        if (rowmasks) mask_next = rowmasks[b_next] >> 16;
-        load_rows(reinterpret_cast<const char *>(sp.base + block_origin(sp, b_next)), mask_next, pre);
-    }
-    for (int k = 0; ai < ai_end; ++k) {
-        const int b = b_next;
-        const unsigned mask = mask_next;
-        const size_t tri_base = offsets[b];
-        const int budget = (int)(offsets[b + 1] - offsets[b]);  // the scan's count for this block
-        VTMC_WAVE_SYNC();
-        store_tile(tile_of(L), pre);
-        if (ai_next < ai_end) {  // prefetch the next block's tile; it lands while this one is processed
-            b_next = active_list[(ablate & 2) ? ai_begin + (k & 3) : ai_next];
-            if (rowmasks) mask_next = rowmasks[b_next] >> 16;
-            load_rows(reinterpret_cast<const char *>(sp.base + block_origin(sp, b_next)), mask_next, pre);
-        }
-        request();  // ticket for the block after next; collected at the bottom of this iteration
-        VTMC_WAVE_SYNC();
-
-        if constexpr (INDEXED)
-            emit_block_indexed<FAST>(L, s_vert, s_own, &s_once[0], tri_base, budget, (size_t)voffsets[b], (int)(voffsets[b + 1] - voffsets[b]), out,
-                                     out_indices, lane, ablate, mask, vm_unused);
-        else if constexpr (ONCE)
-            emit_block_once<FAST>(L, s_vert, &s_once[0], tri_base, budget, b, out, lane, ablate, mask, vm_unused, pc_unused);
-        else
-            emit_block_from_tile<FAST>(L, s_vert, tri_base, budget, b, out, lane, ablate, mask, vm_unused);
-        ai = ai_next;
-        ai_next = collect();
-    }
     }
 }
 
@@ -392,7 +320,7 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
                        void *triangles, int n_cus, const Tuning &tune, unsigned *queue, uint32_t *volume_counts, int n_volumes,
                        hipStream_t stream)
 {
-    const bool once = tune.emit_once && tune.emit_fast_math && tune.emit_async;   // the exact mode stays bit-compatible with the oracle: per-corner evaluation
+    const bool once = tune.emit_once && tune.emit_fast_math;   // the exact mode stays bit-compatible with the oracle: per-corner evaluation
     int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : (once ? 3 : 4);  // 4 x 40 KB of LDS, 128 VGPRs; vertex-once: 3 x 53 KB
     int wgs = n_cus * per_cu;
     wgs = (wgs + 7) & ~7;  // the XCD sweep needs a multiple of 8
@@ -401,15 +329,10 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
     float *o = (float *)triangles;
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
     launch_begin();
-#define VTMC_LAUNCH_SOUP(F, A, ...) hipLaunchKernelGGL((emit_kernel<F, false, A, ##__VA_ARGS__>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes)
-    if (once) VTMC_LAUNCH_SOUP(true, true, true);
-    else if (tune.emit_fast_math) {
-        if (tune.emit_async) VTMC_LAUNCH_SOUP(true, true);
-        else VTMC_LAUNCH_SOUP(true, false);
-    } else {
-        if (tune.emit_async) VTMC_LAUNCH_SOUP(false, true);
-        else VTMC_LAUNCH_SOUP(false, false);
-    }
+#define VTMC_LAUNCH_SOUP(F, O) hipLaunchKernelGGL((emit_kernel<F, false, O>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes)
+    if (once) VTMC_LAUNCH_SOUP(true, true);
+    else if (tune.emit_fast_math) VTMC_LAUNCH_SOUP(true, false);
+    else VTMC_LAUNCH_SOUP(false, false);
 #undef VTMC_LAUNCH_SOUP
     return launch_end();
 }
@@ -428,22 +351,12 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
     dim3 g(wgs), blk(three ? 192 : 256);
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
     launch_begin();
-#define VTMC_LAUNCH_IDX(F, A, W) hipLaunchKernelGGL((emit_kernel<F, true, A, false, W>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_group_log2, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes)
+#define VTMC_LAUNCH_IDX(F, W) hipLaunchKernelGGL((emit_kernel<F, true, false, W>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes)
     if (three) {
-        if (tune.emit_fast_math) {
-            if (tune.emit_async) VTMC_LAUNCH_IDX(true, true, 3);
-            else VTMC_LAUNCH_IDX(true, false, 3);
-        } else {
-            if (tune.emit_async) VTMC_LAUNCH_IDX(false, true, 3);
-            else VTMC_LAUNCH_IDX(false, false, 3);
-        }
-    } else if (tune.emit_fast_math) {
-        if (tune.emit_async) VTMC_LAUNCH_IDX(true, true, 4);
-        else VTMC_LAUNCH_IDX(true, false, 4);
-    } else {
-        if (tune.emit_async) VTMC_LAUNCH_IDX(false, true, 4);
-        else VTMC_LAUNCH_IDX(false, false, 4);
-    }
+        if (tune.emit_fast_math) VTMC_LAUNCH_IDX(true, 3);
+        else VTMC_LAUNCH_IDX(false, 3);
+    } else if (tune.emit_fast_math) VTMC_LAUNCH_IDX(true, 4);
+    else VTMC_LAUNCH_IDX(false, 4);
 #undef VTMC_LAUNCH_IDX
     return launch_end();
 }

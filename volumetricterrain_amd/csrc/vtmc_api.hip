@@ -83,20 +83,6 @@ namespace {
 // One launch of the emit stage on the pending extract's stream, followed by the asynchronous copy of
 // the scan's totals into pinned memory.  The kernel itself refuses to run past its buffers' capacity
 // (it compares the device-resident T / V with the capacities it is handed).
-// The one-launch form of the step (onepass_kernels.hip) on the pending extract's stream.
-int queue_onepass(vtmc_ctx *ctx)
-{
-    const VtmcPending &pe = ctx->pending;
-    const size_t tcap = std::min<size_t>(ctx->tris.bytes / sizeof(vtmc_triangle), 0x7fffffffu);
-    ctx->pending.tcap = tcap;
-    ctx->pending.vcap = 0;
-    uint32_t *vc = pe.n_volumes > 0 ? (uint32_t *)ctx->volcounts.p : nullptr;
-    VTMC_HIP(ctx, launch_onepass(pe.sp, ctx->tables, ctx->partials.p, (uint32_t *)ctx->offsets.p, ctx->tris.p, (uint32_t)tcap, (uint32_t *)ctx->totals.p,
-                                 ctx->h_totals_dev, vc, pe.n_volumes, ctx->n_cus, ctx->tune, pe.stream));
-    VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], pe.stream));
-    return VTMC_OK;
-}
-
 int queue_emit(vtmc_ctx *ctx, bool retry)
 {
     const VtmcPending &pe = ctx->pending;
@@ -184,22 +170,6 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
                        ((sp.sx == 1 && sp.nx >= 32) || (sp.sx != 1 && sp.sz == 1 && sp.nbz * 8 >= 32));
 
     ctx->h_totals[8] = 0u;   // the scan's look-back time-out word
-    if (dense && ctx->tune.one_pass && !indexed && sp.sx == 1 && !(ctx->tune.fill_keeps_signs && ctx->sign_of.valid)) {
-        // one launch: every wave classifies a brick, takes its place in the output from a chained scan and emits it (onepass_kernels.hip)
-        if (int rc = ensure(ctx, ctx->partials, std::max(onepass_ctrl_bytes(sp), sizeof(unsigned long long) * 2 * ctrl_words))) return rc;
-        VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
-        if (ctx->tune.stage_events) {
-            VTMC_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
-            VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
-        }
-        pe.one_pass = true;
-        pe.active = true;
-        pe.launched = true;
-        ctx->pending = pe;
-        const int rc = queue_onepass(ctx);
-        if (rc) ctx->pending = VtmcPending{};
-        return rc;
-    }
     unsigned long long *ctrl = (unsigned long long *)ctx->partials.p;
     const int n_ctrl = (int)(ctrl_words * (indexed ? 2 : 1));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
@@ -277,10 +247,6 @@ int extract_finish(vtmc_ctx *ctx, int64_t *tri_count)
             }
             if ((size_t)V > ctx->pending.vcap)
                 if (int rc = ensure(ctx, ctx->verts, sizeof(vtmc_vertex) * ((size_t)V + (size_t)V / 8 + 1024))) return rc;
-            if (pe.one_pass) {
-                if (int rc = queue_onepass(ctx)) return rc;
-                continue;
-            }
             VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], pe.stream));
             if (int rc = queue_emit(ctx, true)) return rc;
         }
@@ -788,32 +754,38 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
 {
     if (!ctx || !key) return VTMC_ERR_INVALID_ARG;
     const std::string k(key);
-    if (k == "emit_fast_math") ctx->tune.emit_fast_math = value;
-    else if (k == "emit_sub_log2") ctx->tune.emit_sub_log2 = value < 0 ? 0 : (value > 4 ? 4 : value);
-    else if (k == "emit_dynamic") ctx->tune.emit_dynamic = value;
-    else if (k == "emit_async") ctx->tune.emit_async = value;
-    else if (k == "emit_once") ctx->tune.emit_once = value;
-    else if (k == "emit_idx_waves") ctx->tune.emit_idx_waves = value;
-    else if (k == "one_pass") ctx->tune.one_pass = value;
-    else if (k == "one_pass_unit") ctx->tune.one_pass_unit = value;
-    else if (k == "one_pass_depth") ctx->tune.one_pass_depth = value;
-    else if (k == "one_pass_prefetch") ctx->tune.one_pass_prefetch = value;
-    else if (k == "emit_ablate") ctx->tune.emit_ablate = value;
-    else if (k == "classify_ablate") ctx->tune.classify_ablate = value;
-    else if (k == "emit_row_masks") ctx->tune.emit_row_masks = value;
-    else if (k == "density_ablate") ctx->tune.density_ablate = value;
-    else if (k == "density_wgs_per_cu") ctx->tune.density_wgs_per_cu = value;
-    else if (k == "invalidate_signs") ctx->sign_of.valid = false;   // the caller wrote to (or re-used the address of) a buffer the last fill left sign bits for
-    else if (k == "fill_keeps_signs") {
-        ctx->tune.fill_keeps_signs = value;
+    // every key below selects code that tests/test_tuning_matrix.py compares with the oracle; a value outside a key's range is refused
+    auto ranged = [&](int &field, int lo, int hi) {
+        if (value < lo || value > hi) return fail(ctx, VTMC_ERR_INVALID_ARG, "tuning key '%s': %d is outside [%d, %d]", key, value, lo, hi);
+        field = value;
+        return (int)VTMC_OK;
+    };
+    if (k == "emit_fast_math") return ranged(ctx->tune.emit_fast_math, 0, 1);
+    if (k == "emit_once") return ranged(ctx->tune.emit_once, 0, 1);
+    if (k == "emit_dynamic") return ranged(ctx->tune.emit_dynamic, 0, 1);
+    if (k == "emit_sub_log2") return ranged(ctx->tune.emit_sub_log2, 0, 4);
+    if (k == "emit_row_masks") return ranged(ctx->tune.emit_row_masks, 0, 1);
+    if (k == "emit_wgs_per_cu") return ranged(ctx->tune.emit_wgs_per_cu, 0, 8);
+    if (k == "emit_idx_waves") return ranged(ctx->tune.emit_idx_waves, 3, 4);
+    if (k == "classify_wgs_per_cu") return ranged(ctx->tune.classify_wgs_per_cu, 0, 7);
+    if (k == "density_wgs_per_cu") return ranged(ctx->tune.density_wgs_per_cu, 0, 8);
+    if (k == "gather_beside") return ranged(ctx->tune.gather_beside, 0, 1);
+    if (k == "stage_events") return ranged(ctx->tune.stage_events, 0, 1);
+    if (k == "invalidate_signs") {   // the caller wrote to (or re-used the address of) a buffer the last fill left sign bits for
         ctx->sign_of.valid = false;
+        return VTMC_OK;
     }
-    else if (k == "gather_beside") ctx->tune.gather_beside = value;
-    else if (k == "stage_events") ctx->tune.stage_events = value;
-    else if (k == "classify_wgs_per_cu") ctx->tune.classify_wgs_per_cu = value;
-    else if (k == "emit_group_log2") ctx->tune.emit_group_log2 = value < 0 ? 0 : (value > 8 ? 8 : value);
-    else if (k == "emit_wgs_per_cu") ctx->tune.emit_wgs_per_cu = value;
-    else return fail(ctx, VTMC_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
+    if (k == "fill_keeps_signs") {
+        ctx->sign_of.valid = false;
+        return ranged(ctx->tune.fill_keeps_signs, 0, 1);
+    }
+#ifdef VTMC_DIAGNOSTICS   // output INVALID: diagnostic builds only (the product's kernels do not contain these branches)
+    if (k == "emit_ablate") ctx->tune.emit_ablate = value;
+    else if (k == "classify_ablate") ctx->tune.classify_ablate = value;
+    else if (k == "density_ablate") ctx->tune.density_ablate = value;
+    else
+#endif
+    return fail(ctx, VTMC_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
     return VTMC_OK;
 }
 

@@ -23,7 +23,6 @@ struct VtmcPending {
     hipStream_t stream = nullptr;
     size_t tcap = 0, vcap = 0;  // capacities the last emit launch was given
     bool scan_event = false;    // ev[2] was recorded behind this extract's scan
-    bool one_pass = false;      // the step was queued as one launch (onepass_kernels.hip): a regrow runs all of it again
     bool counts_early = false;  // the per-volume counts were final when ev[2] (end of the scan) was recorded
 };
 

@@ -56,31 +56,35 @@ struct SignVolume {
     int plane_words = 0, dx = 0, dz = 0;
 };
 
-// A/B knobs (vtmc_set_tuning); defaults are the shipped configuration.
+// The *_ablate keys switch parts of a kernel off (the output is then INVALID): they exist in diagnostic builds only
+// (-DVTMC_DIAGNOSTICS: tools/build_diagnostics.py, loaded through VTMC_LIB); the product library compiles every such branch
+// out of its kernels and vtmc_set_tuning answers VTMC_ERR_INVALID_ARG for the keys.
+#ifdef VTMC_DIAGNOSTICS
+#define VTMC_ABLATE(v) (v)
+#else
+#define VTMC_ABLATE(v) 0
+#endif
+
+// A/B knobs (vtmc_set_tuning); defaults are the shipped configuration.  Every key the product library accepts is compared with the oracle
+// by tests/test_tuning_matrix.py.
 struct Tuning {
     int emit_fast_math = 1;   // 1: v_rcp/v_rsq (<= ~5e-7 from exact); 0: correctly rounded, bit-compatible with the oracle
     int emit_wgs_per_cu = 0;   // 0: the kernel's own residency (4 for the soup, 3 for the indexed output)
     int emit_sub_log2 = 1;    // dynamic mode: 2^s ticket counters per XCD
     int emit_dynamic = 1;     // per-XCD ticket counters instead of a static round-robin over the active list
-    int emit_ablate = 0;      // diagnostics only: 1 skip stores, 2 re-read hot tiles, 4 skip vertex math (output invalid)
-    int classify_ablate = 0;  // diagnostics only: 1 no halo rows (output invalid)
+    int emit_ablate = 0;      // diagnostic builds only: 1 skip stores, 2 re-read hot tiles, 4 skip vertex math (output invalid)
+    int classify_ablate = 0;  // diagnostic builds only: 1 no halo rows (output invalid)
     int classify_wgs_per_cu = 3;   // residency cap of the streaming classify kernel (0: none = 7 workgroups per CU; 3 measured best, A/B in profiles/r02c)
     int emit_row_masks = 1;   // emit loads only the tile rows next to cells with triangles (masks from classify)
-    int emit_group_log2 = 0;  // each wave takes 2^g consecutive active-list entries per round
-    int density_ablate = 0;   // diagnostics only: 1 the sampler skips its stores (output invalid)
+    int density_ablate = 0;   // diagnostic builds only: 1 the sampler skips its stores (output invalid)
     int fill_keeps_signs = 0;   // 1: a z-walk density fill also leaves the samples' sign bits; an extract of the same, UNMODIFIED buffer by this
                                 // context then classifies from them (1/32 of the bytes) -- the streaming driver's setting
     int density_wgs_per_cu = 0;   // residency cap of the column sampler (0: four workgroups per CU); 3 leaves room for a concurrent extract
     int stage_events = 1;     // 1: events between the three kernels (vtmc_last_stage_ms per stage); 0: only around the whole step
     int gather_beside = 0;    // 1: the all-gather of a queued extract runs on a second stream beside the emit kernel (opt-in: never run with a world > 1); 0: behind it, on the caller's stream
-    int emit_async = 1;       // 1: tile prefetch and tickets outside the compiler's vmcnt bookkeeping, a block's stores are never waited for (emit_kernels.hip); 0: round 2's loop
     int emit_once = 1;        // 1 (soup, fast math): every welded vertex of a block is evaluated once into LDS, records expanded from there; 0: per triangle corner
     int emit_spare_wgs = 0;   // workgroups the emit launch leaves free (one per XCD: room for the collective's kernel beside it)
     int emit_idx_waves = 4;   // indexed output: waves per emit workgroup (4: four workgroups = 16 waves per CU; 3: six = 18 -- measured no faster: the kernel is at its memory ceiling from 15 waves on)
-    int one_pass = 0;         // 1 (soup, dense x-fastest batches): classify + scan + emit in ONE launch (onepass_kernels.hip); 0: three launches
-    int one_pass_depth = 0;   // one-pass: bricks a wave classifies before it emits the oldest of them (1-3; 0: 2)
-    int one_pass_prefetch = 0;   // one-pass: 1 = the next ticket is requested beside the last block of the brick being emitted (measured: +20 %, the held brick stalls the bricks behind it)
-    int one_pass_unit = 0;    // one-pass: look-back groups (64 bricks) per work unit of an XCD's ticket counter (0: a volume of the batch, or 8)
 };
 
 // scan scratch layout
@@ -129,21 +133,6 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
                                uint32_t tri_capacity,
                                uint32_t vert_capacity, void *vertices, void *indices, int n_cus, const Tuning &tune, unsigned *queue,
                                uint32_t *volume_counts, int n_volumes, hipStream_t stream);
-
-// onepass_kernels.hip: the whole step of a dense x-fastest soup batch in one launch.  `ctrl`: onepass_ctrl_bytes(sp) bytes of scratch (zeroed
-// by the launch); totals / host_totals as launch_scan_fused leaves them ({T saturating, 0, T lo, T hi}, [8] = 1 on a look-back time-out);
-// triangles of a block that would pass `capacity` are not written (the host grows the buffer and runs the step again).
-struct OnePassCtrl {
-    unsigned *queue;            // 8 ticket counters, 256 bytes apart
-    unsigned *err;              // look-back time-out
-    unsigned long long *gsum;   // per group of 64 bricks: published bricks << 40 | their triangles
-    unsigned long long *gstat;  // per group: state << 62 (1 aggregate, 2 inclusive prefix) | triangles
-    unsigned *bstat;            // per brick: 1 << 31 | triangles
-};
-size_t onepass_ctrl_bytes(const BlockSpace &sp);
-hipError_t launch_onepass(const BlockSpace &sp, const DeviceTables &tb, void *ctrl, uint32_t *offsets, void *triangles, uint32_t capacity,
-                          uint32_t *totals, uint32_t *host_totals, uint32_t *volume_counts, int n_volumes, int n_cus, const Tuning &tune,
-                          hipStream_t stream);
 
 // terrain.hip: device-resident density grid with the reference's CSG write semantics.
 struct TerrainShape {
