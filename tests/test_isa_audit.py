@@ -17,3 +17,21 @@ def test_no_compiler_instruction_touches_a_register_with_an_asm_load_in_flight()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_audit.py")], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-4000:] + p.stderr[-2000:]
     assert "asm loads, 0 findings" in p.stdout and "FINDING" not in p.stdout
+
+
+def test_audit_follows_control_flow_and_still_catches_a_touch():
+    """The audit walks the control-flow graph, not the text: hipcc may place the block that stores the landed tile BEHIND the block that
+    issues the next tile's loads.  (i) such a placement is clean; (ii) a compiler move of a register whose load is in flight is found
+    on whichever path reaches it."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_audit
+    wait = ["\t;;#ASMSTART", "\ts_waitcnt vmcnt(48)", "\ts_waitcnt vmcnt(0)", "\t;;#ASMEND"]
+    load = ["\t;;#ASMSTART", "\tglobal_load_dword v13, v1, s[22:23]", "\t;;#ASMEND"]
+    clean = ["k:"] + load + [".LBB0_1:"] + wait + ["\ts_cbranch_execnz .LBB0_3", ".LBB0_2:"] + load + ["\ts_cbranch_scc1 .LBB0_4", "\ts_branch .LBB0_1",
+             ".LBB0_3:", "\tds_write_b32 v58, v13", "\ts_branch .LBB0_2", ".LBB0_4:"] + wait + ["\ts_endpgm"]
+    n, problems = isa_audit.audit_kernel("k", clean)
+    assert n == 2 and not [p for p in problems if "in flight" in p], problems
+    dirty = list(clean)
+    dirty.insert(dirty.index("\ts_cbranch_scc1 .LBB0_4"), "\tv_mov_b32_e32 v5, v13")
+    _, problems = isa_audit.audit_kernel("k", dirty)
+    assert any("touches v[13]" in p for p in problems), problems

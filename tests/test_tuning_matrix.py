@@ -121,7 +121,7 @@ def test_sampler_residency_cap_matches_cpu_twin(ex, oracle_mod):
     d = torch.empty(dim ** 3, dtype=torch.float32, device="cuda")
     got = {}
     try:
-        for cap in (0, 1, 3):
+        for cap in (0, 2, 3):
             ex.set_tuning(density_wgs_per_cu=cap)
             ex.density_fill_device(vt.density_params("fbm8", n), [[0, 0, 0]], (dim, dim, dim), (1, dim, dim * dim), 0, d.data_ptr())
             got[cap] = d.cpu().numpy().reshape(dim, dim, dim).transpose(2, 1, 0).copy()
@@ -138,7 +138,7 @@ def test_refused_keys_and_values(ex):
     for key, value in (("one_pass", 1), ("one_pass_depth", 2), ("one_pass_unit", 1), ("one_pass_prefetch", 1), ("emit_async", 0),
                        ("emit_group_log2", 2), ("emit_ablate", 1), ("classify_ablate", 1), ("density_ablate", 1), ("no_such_key", 0),
                        ("emit_idx_waves", 5), ("emit_idx_waves", 2), ("emit_sub_log2", 5), ("emit_sub_log2", -1), ("emit_wgs_per_cu", 9),
-                       ("classify_wgs_per_cu", 8), ("emit_fast_math", 2), ("emit_once", -1)):
+                       ("classify_wgs_per_cu", 8), ("classify_wgs_per_cu", 1), ("density_wgs_per_cu", 1), ("density_wgs_per_cu", 4), ("emit_fast_math", 2), ("emit_once", -1)):
         with pytest.raises(vt.VtmcError) as e:
             ex.set_tuning(**{key: value})
         assert e.value.code == -1, key   # VTMC_ERR_INVALID_ARG

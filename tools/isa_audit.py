@@ -61,38 +61,103 @@ def regs_of(operand_text):
 
 
 def audit_kernel(name, lines):
-    """Linear walk: a register is `pending` from the asm statement that loads it to the next asm statement that holds an
-    `s_waitcnt vmcnt` (the counted wait sits at the head of the main loop and once more behind it, so the linear order covers
-    a load's whole way round the loop).  Nothing but inline asm may touch a pending register."""
-    problems = []
-    pending = {}
-    n_loads = 0
-    in_asm = False
-    block = []
+    """Dataflow over the kernel's control-flow graph (hipcc places basic blocks freely: the tile's way into LDS may stand BEHIND the next
+    tile's loads in the text although it runs before them, so a linear walk of the text is not the order of execution).  A register is
+    `pending` from the asm statement that loads it until an asm statement that holds an `s_waitcnt vmcnt` (the counted wait at the head
+    of the main loop, and once more behind it); the pending sets are propagated along every edge to a fixed point, and nothing but
+    inline asm may touch a register that is pending on ANY path that reaches the instruction."""
+    # units: ("asm", [lines], line no) | ("ins", code, line no) | ("label", name, line no)
+    units, in_asm, block, start = [], False, [], 0
     for i, l in enumerate(lines):
         if "#ASMSTART" in l:
-            in_asm, block = True, []
+            in_asm, block, start = True, [], i
             continue
         if "#ASMEND" in l:
             in_asm = False
-            if any("s_waitcnt vmcnt" in b for b in block):
-                pending = {}
-            for b in block:
-                m = re.match(r"\s*(global_load_dword(?:x2)?|global_atomic_add)\s+(v\d+|v\[\d+:\d+\])\s*,", b)
-                if m:
-                    for r in regs_of(m.group(2)):
-                        pending[r] = i
-                    n_loads += 1
+            units.append(("asm", block, start))
             continue
         if in_asm:
             block.append(l)
             continue
         code = l.split(";")[0].strip()
-        if not code or code.endswith(":") or code.startswith("."):
+        if not code or code.startswith("."):
+            m = re.match(r"^(\.LBB\w+):", l)
+            if m:
+                units.append(("label", m.group(1), i))
             continue
-        touched = regs_of(code) & set(pending)
-        if touched:
-            problems.append("%s: line %d touches v%s while its asm load is in flight: %s" % (name[:60], i, sorted(touched), code))
+        if code.endswith(":"):
+            units.append(("label", code[:-1], i))
+            continue
+        units.append(("ins", code, i))
+    # basic blocks
+    blocks, cur = [], []
+    label_of = {}
+    for u in units:
+        if u[0] == "label":
+            if cur:
+                blocks.append(cur)
+                cur = []
+            label_of[u[1]] = len(blocks)
+            continue
+        cur.append(u)
+        if u[0] == "ins" and re.match(r"s_(cbranch\w*|branch|endpgm|setpc_b64)\b", u[1]):
+            blocks.append(cur)
+            cur = []
+    if cur:
+        blocks.append(cur)
+    succ = []
+    for bi, blk in enumerate(blocks):
+        last = blk[-1] if blk else None
+        out = []
+        if last and last[0] == "ins":
+            op = last[1].split()[0]
+            tgt = last[1].split()[-1]
+            if op == "s_branch":
+                out = [label_of[tgt]] if tgt in label_of else []
+            elif op.startswith("s_cbranch"):
+                out = ([label_of[tgt]] if tgt in label_of else []) + ([bi + 1] if bi + 1 < len(blocks) else [])
+            elif op in ("s_endpgm", "s_setpc_b64"):
+                out = []
+            else:
+                out = [bi + 1] if bi + 1 < len(blocks) else []
+        else:
+            out = [bi + 1] if bi + 1 < len(blocks) else []
+        succ.append(out)
+
+    n_loads = 0
+
+    def transfer(blk, pending, report):
+        nonlocal n_loads
+        pending = set(pending)
+        for kind, body, i in blk:
+            if kind == "asm":
+                if any("s_waitcnt vmcnt" in b for b in body):
+                    pending = set()
+                for b in body:
+                    m = re.match(r"\s*(global_load_dword(?:x2)?|global_atomic_add)\s+(v\d+|v\[\d+:\d+\])\s*,", b)
+                    if m:
+                        pending |= regs_of(m.group(2))
+                        if report is not None:
+                            n_loads += 1
+                continue
+            touched = regs_of(body) & pending
+            if touched and report is not None:
+                report.append("%s: line %d touches v%s while its asm load is in flight: %s" % (name[:60], i, sorted(touched), body))
+        return pending
+
+    pend_in = [set() for _ in blocks]
+    work = list(range(len(blocks)))
+    while work:
+        bi = work.pop(0)
+        out = transfer(blocks[bi], pend_in[bi], None)
+        for sj in succ[bi]:
+            if not out <= pend_in[sj]:
+                pend_in[sj] |= out
+                if sj not in work:
+                    work.append(sj)
+    problems = []
+    for bi, blk in enumerate(blocks):
+        transfer(blk, pend_in[bi], problems)
     problems += sgpr_hazards(name, lines)
     if n_loads:
         problems += compiler_waits_in_loop(name, lines)

@@ -263,8 +263,8 @@ __device__ __forceinline__ unsigned long long scan_pack(unsigned long long state
 // DUAL: the welded-vertex counts of the indexed output ride along (second count array, second status word
 // per tile, second offsets array): one launch for both scans.
 template <bool DUAL>
-__global__ __launch_bounds__(256) void scan_fused_kernel(const uint32_t *__restrict__ counts, int n, uint32_t *__restrict__ offsets,
-                                                          int32_t *__restrict__ active_list, unsigned long long *__restrict__ ctrl,
+__global__ __launch_bounds__(256) void scan_fused_kernel(BlockSpace sp, const uint32_t *__restrict__ counts, int n, uint32_t *__restrict__ offsets,
+                                                          BlockDesc *__restrict__ active, unsigned long long *__restrict__ ctrl,
                                                           uint32_t *__restrict__ totals, uint32_t *__restrict__ host_totals,
                                                           uint32_t *__restrict__ zero_words, int n_zero,
                                                           const uint32_t *__restrict__ vcounts, uint32_t *__restrict__ voffsets,
@@ -290,9 +290,9 @@ __global__ __launch_bounds__(256) void scan_fused_kernel(const uint32_t *__restr
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int i = base + k;
-        c[k] = i < n ? counts[i] & kCountMask : 0u;
-        sum += c[k];
-        act += c[k] != 0u;
+        c[k] = i < n ? counts[i] : 0u;   // triangles | row mask << 16
+        sum += c[k] & kCountMask;
+        act += (c[k] & kCountMask) != 0u;
         if (DUAL) {
             vc[k] = i < n ? vcounts[i] : 0u;
             vsum += vc[k];
@@ -426,8 +426,18 @@ __global__ __launch_bounds__(256) void scan_fused_kernel(const uint32_t *__restr
         const int i = base + k;
         if (i < n) {
             offsets[i] = off;
-            if (active_list && c[k] != 0u) active_list[aoff++] = i;
-            off += c[k];
+            if (active && (c[k] & kCountMask) != 0u) {   // the emit kernel's work item: everything it needs to know about the block in one 32-byte record
+                BlockDesc d;
+                d.b = (uint32_t)i;
+                d.tri_base = off;
+                d.cnt_mask = c[k];
+                d.vert_base = DUAL ? voff : 0u;
+                d.origin = block_origin(sp, i);
+                d.vert_cnt = DUAL ? vc[k] : 0u;
+                d.pad = 0u;
+                active[aoff++] = d;
+            }
+            off += c[k] & kCountMask;
             if (i == n - 1) offsets[n] = off;
             if (DUAL) {
                 voffsets[i] = voff;
@@ -500,7 +510,7 @@ hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, u
     return launch_end();
 }
 
-hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list, unsigned long long *ctrl,
+hipError_t launch_scan_fused(const BlockSpace &sp, const uint32_t *counts, int n_blocks, uint32_t *offsets, BlockDesc *active, unsigned long long *ctrl,
                              uint32_t *totals, uint32_t *host_totals, uint32_t *zero_words, int n_zero, const uint32_t *vcounts_or_null,
                              uint32_t *voffsets, uint32_t *vtotals, uint32_t *volume_counts_or_null, int bpv, hipStream_t stream)
 {
@@ -509,10 +519,10 @@ hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *off
     const int tpv = (volume_counts_or_null && bpv > 0 && bpv % kScanTile == 0) ? bpv / kScanTile : 0;
     launch_begin();
     if (vcounts_or_null)
-        hipLaunchKernelGGL((scan_fused_kernel<true>), dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, offsets, active_list, ctrl, totals,
+        hipLaunchKernelGGL((scan_fused_kernel<true>), dim3(n_tiles), dim3(256), 0, stream, sp, counts, n_blocks, offsets, active, ctrl, totals,
                            host_totals, zero_words, n_zero, vcounts_or_null, voffsets, vstatus, vtotals, volume_counts_or_null, tpv);
     else
-        hipLaunchKernelGGL((scan_fused_kernel<false>), dim3(n_tiles), dim3(256), 0, stream, counts, n_blocks, offsets, active_list, ctrl, totals,
+        hipLaunchKernelGGL((scan_fused_kernel<false>), dim3(n_tiles), dim3(256), 0, stream, sp, counts, n_blocks, offsets, active, ctrl, totals,
                            host_totals, zero_words, n_zero, nullptr, nullptr, nullptr, nullptr, volume_counts_or_null, tpv);
     return launch_end();
 }

@@ -48,7 +48,7 @@ struct __attribute__((aligned(16))) EmitLds2 {
     float tile[1000];
     unsigned slot[kSlotCap];        // triangle slot -> cell | edge triple << 9
     unsigned short acell[512];      // active cells of the block, ascending cell id
-    unsigned char cases[512];
+    unsigned char cases[512];       // cases[i]: the case of cell acell[i] (pass 1 holds it in registers anyway)
     float stage[kStageTris * kTriDwords + 4];
 };
 static_assert(sizeof(EmitLds2) % 16 == 0 && offsetof(EmitLds2, stage) % 16 == 0, "stage must stay 16-byte aligned");
@@ -130,10 +130,23 @@ __device__ __forceinline__ void normalise(float d[3])
 // quad, i.e. body_lo + 256 p < body_hi): a lower bound of the wave's vector-memory instructions, which the counted wait of the
 // asynchronous tile prefetch needs (emit_kernels.hip, wait_vm_at_most); the two edge stores are left out of it.
 template <int MAX_PASSES = 3>   // 256 dwords per pass: a bound known at compile time keeps the loop's bookkeeping out of the scalar unit
-__device__ __forceinline__ void stream_out_range(const float *stage, float *__restrict__ gal, int lo, int hi, int lane, int ablate, int &vm_issued)
+__device__ __forceinline__ void stream_out_range(const float *stage, float *__restrict__ gal, int lo, int hi, int lane, int ablate, int &vm_issued,
+                                                 int stage_last_quad)
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const int body_lo = (lo + 3) & ~3, body_hi = hi & ~3;
+    // every LDS read of the call is issued before the first store (a read inside its store's conditional is a round trip of its own: three
+    // `ds_read_b128 -> s_waitcnt -> global_store` chains per round in round 4's ISA); a lane beyond the range reads the staging area's last quad
+    v4f v[MAX_PASSES];
+#pragma unroll
+    for (int pass = 0; pass < MAX_PASSES; ++pass) {
+        const int q4 = body_lo + 4 * lane + 256 * pass;
+        v[pass] = *reinterpret_cast<const v4f *>(stage + (q4 < stage_last_quad ? q4 : stage_last_quad));
+    }
+    const int k = lane & 3;
+    const int idx = lane < 4 ? lo + k : body_hi + k;
+    const bool on = lane < 4 ? (idx < body_lo && idx < hi) : (lane < 8 && idx < hi && idx >= body_lo);
+    const float edge = stage[on ? idx : lo];
     if (!(ablate & 1)) {
         const int n_pass = body_hi > body_lo ? (body_hi - body_lo + 255) >> 8 : 0;
         vm_issued += n_pass < MAX_PASSES ? n_pass : MAX_PASSES;
@@ -141,17 +154,13 @@ __device__ __forceinline__ void stream_out_range(const float *stage, float *__re
         for (int pass = 0; pass < MAX_PASSES; ++pass) {
             const int q4 = body_lo + 4 * lane + 256 * pass;
             if (q4 < body_hi) {
-                const v4f v = *reinterpret_cast<const v4f *>(stage + q4);
                 v4f *p = reinterpret_cast<v4f *>(gal + q4);
-                if (ablate & 16) __builtin_nontemporal_store(v, p);   // diagnostics: streaming hint (no faster at four workgroups per CU)
-                else *p = v;
+                if (ablate & 16) __builtin_nontemporal_store(v[pass], p);   // diagnostics: streaming hint (no faster at four workgroups per CU)
+                else *p = v[pass];
             }
         }
     }
-    const int k = lane & 3;
-    const int idx = lane < 4 ? lo + k : body_hi + k;
-    const bool on = lane < 4 ? (idx < body_lo && idx < hi) : (lane < 8 && idx < hi && idx >= body_lo);
-    if (on) __builtin_nontemporal_store(stage[idx], gal + idx);
+    if (on) __builtin_nontemporal_store(edge, gal + idx);
 }
 
 // The 64 records of a batch (lane r holds record r in `rec`; `on`: the lane has one) leave through a staging area
@@ -179,7 +188,7 @@ __device__ __forceinline__ void stream_batch76(float *stage, const float (&rec)[
         // stream coordinates of this round, and the same relative to the staging area (which starts at 608 h)
         const int lo = h == 0 ? sh : split, hi = (h == 0 && cnt > 32) ? split : end;
         const int base = 32 * kTriDwords * h;
-        stream_out_range<3>(stage - base, gal, lo, hi, lane, ablate, vm_issued);
+        stream_out_range<3>(stage - base, gal, lo, hi, lane, ablate, vm_issued, base + (kStageTris * kTriDwords & ~3));
     }
     VTMC_WAVE_SYNC();
 }
@@ -209,37 +218,39 @@ __device__ __forceinline__ void emit_flush2(EmitLds2 *L, int pending, size_t tri
             const unsigned e[3] = {trip & 15u, (trip >> 8) & 15u, (trip >> 4) & 15u};
             const float *tile = L->tile;
             EdgeSite es[3];
-            float va[3], vb[3];
+            float va[3], vb[3], ga[3][3], gb[3][3];
+            // One round of LDS reads per vertex: the samples at both endpoints of the edge and their forward neighbours.  t lies in [0, 1], so
+            // floor(P) and ceil(P) of MarchingCube.compute:71-72 are the edge's endpoints a or b themselves: the two lattice gradients the
+            // trilinear fetch blends (SampleNormal.compute:27-30) are known before t is -- which of them is c0 / c1 is a select afterwards.
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 es[k] = edge_site(cx, cy, cz, tcell, e[k]);
                 va[k] = tile[es[k].ta];
                 vb[k] = tile[es[k].tb];
+                ga[k][0] = va[k] - tile[es[k].ta + 1];
+                ga[k][1] = va[k] - tile[es[k].ta + 10];
+                ga[k][2] = va[k] - tile[es[k].ta + 100];
+                gb[k][0] = vb[k] - tile[es[k].tb + 1];
+                gb[k][1] = vb[k] - tile[es[k].tb + 10];
+                gb[k][2] = vb[k] - tile[es[k].tb + 100];
             }
-            float q[3], w[3], g0[3][3], g1[3][3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 // t lies in [0,1] (the endpoints differ in sign class); the 1-ulp v_rcp can land a hair
                 // outside, which would push floor/ceil one lattice point beyond the edge -- clamp it back
                 const float t = FAST ? __builtin_amdgcn_fmed3f(-va[k] * __builtin_amdgcn_rcpf(vb[k] - va[k]), 0.0f, 1.0f)
                                      : (-va[k]) / (vb[k] - va[k]);
-                q[k] = (float)es[k].iak + (es[k].back ? -t : t);
-                const float fq = floorf(q[k]);
-                w[k] = q[k] - fq;
-                const int l0 = es[k].ta + ((int)fq - es[k].iak) * es[k].sk;
-                const int l1 = es[k].ta + ((int)ceilf(q[k]) - es[k].iak) * es[k].sk;
-                lattice_gradient(tile, l0, g0[k]);
-                lattice_gradient(tile, l1, g1[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                normalise<FAST>(g0[k]);
-                normalise<FAST>(g1[k]);
+                const float q = (float)es[k].iak + (es[k].back ? -t : t);
+                const float fq = floorf(q);
+                const float w = q - fq;
+                const bool c0_at_b = ((int)fq - es[k].iak) != 0, c1_at_b = ((int)ceilf(q) - es[k].iak) != 0;   // offset 0: endpoint a; +-1: endpoint b
+                normalise<FAST>(ga[k]);
+                normalise<FAST>(gb[k]);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    rec[3 * k + c] = es[k].axis == (unsigned)c ? q[k] : (float)es[k].ia[c];
-                    rec[9 + 3 * k + c] = FAST ? __builtin_fmaf(w[k], g1[k][c] - g0[k][c], g0[k][c])
-                                              : g0[k][c] + w[k] * (g1[k][c] - g0[k][c]);
+                    const float g0 = c0_at_b ? gb[k][c] : ga[k][c], g1 = c1_at_b ? gb[k][c] : ga[k][c];
+                    rec[3 * k + c] = es[k].axis == (unsigned)c ? q : (float)es[k].ia[c];
+                    rec[9 + 3 * k + c] = FAST ? __builtin_fmaf(w, g1 - g0, g0) : g0 + w * (g1 - g0);
                 }
             }
         }
@@ -255,43 +266,44 @@ __device__ __forceinline__ unsigned cell_case(const float *tile, unsigned cell)
     return layer_nibble(tile, t2, cz) | (layer_nibble(tile, t2, cz + 1) << 4);
 }
 
-// Pass 1 of a block: compaction of the cells that hold triangles, ascending cell id, IN MASK SPACE.  A lane compares the four samples
-// under its cell column (x, y) of a sample layer with 0 (strict '>' as CollectTriNum.compute:50; NaN => outside); each v_cmp leaves the
-// wave's 64 answers in a scalar register pair, so "all eight corners equal?" (case 0x00 or 0xFF, CollectTriNum.compute:48-51: no
-// triangles) is four scalar or / and per sample layer and three per cell layer, the active cells of a layer are the EXEC mask of its
-// compaction store, and no lane ever assembles a case it will not use -- 4 vector instructions per sample layer + 4 per live cell layer
-// instead of ~20 per cell layer.  The case of an active cell is derived where it is needed (cell_case).
-// rowmask bits 0-7 / 8-15: the y / z layers that hold such cells (0xFFFF = unknown): a dead z layer costs nothing (wave-uniform skip),
-// and the sample plane between two live layers is classified once.
-__device__ __forceinline__ int compact_active_cells(const float *tile, unsigned short *acell, int lane, unsigned rowmask)
+// Pass 1 of a block: compaction of the cells that hold triangles, ascending cell id, with their cases.  A lane owns the cell column
+// (x, y) = (lane & 7, lane >> 3).  All 36 samples under the column's nine layers are read UP FRONT (18 ds_read2_b32 behind one
+// another, one wait: round 4's form read a layer, waited, compared, read the next -- 18 LDS round trips in a row, 2 400 cycles per
+// block); the lane keeps the four sign bits of every sample layer as a nibble (strict '>' as CollectTriNum.compute:50; NaN => outside),
+// a cell's case is two nibbles (CollectTriNum.compute:27-51), "has triangles" is case != 0x00 and != 0xFF, and one ballot per cell
+// layer compacts the cells -- each leaves its id and its case, so that no later pass reads the eight corners again.
+// rowmask bits 0-7 / 8-15: the y / z layers that hold such cells (0xFFFF = unknown): only rows next to them were fetched (the others
+// hold stale values), a dead z layer is skipped as a whole (wave-uniform).
+__device__ __forceinline__ int compact_active_cells(const float *tile, unsigned short *acell, unsigned char *acase, int lane, unsigned rowmask)
 {
     const float *p0 = tile + (lane & 7) + 10 * (lane >> 3);
-    const u64 y_live = __builtin_amdgcn_ballot_w64(((rowmask >> (lane >> 3)) & 1u) != 0u);
-    auto layer_masks = [&](int z, u64 &any, u64 &all) {   // over the 2 x 2 samples of sample layer z under every cell column
+    float sm[9][4];
+#pragma unroll
+    for (int z = 0; z < 9; ++z) {
         const float *p = p0 + 100 * z;
-        const u64 a = __builtin_amdgcn_ballot_w64(p[0] > 0.f), b = __builtin_amdgcn_ballot_w64(p[1] > 0.f);
-        const u64 c = __builtin_amdgcn_ballot_w64(p[10] > 0.f), d = __builtin_amdgcn_ballot_w64(p[11] > 0.f);
-        any = (a | b) | (c | d);
-        all = (a & b) & (c & d);
-    };
+        sm[z][0] = p[0];
+        sm[z][1] = p[1];
+        sm[z][2] = p[11];
+        sm[z][3] = p[10];
+    }
+    unsigned nib[9];   // corners 0, 1, 2, 3 of CollectTriNum.compute:27-31 at sample layer z
+#pragma unroll
+    for (int z = 0; z < 9; ++z)
+        nib[z] = (unsigned)(sm[z][0] > 0.f) | ((unsigned)(sm[z][1] > 0.f) << 1) | ((unsigned)(sm[z][2] > 0.f) << 2) | ((unsigned)(sm[z][3] > 0.f) << 3);
+    const bool y_live = ((rowmask >> (lane >> 3)) & 1u) != 0u;
     int n_act = 0;
-    u64 any_lo = 0, all_lo = 0;
-    bool have_lo = false;
 #pragma unroll
     for (int z = 0; z < 8; ++z) {
-        if (!((rowmask >> (8 + z)) & 1u)) {   // wave-uniform
-            have_lo = false;
-            continue;
+        if (!((rowmask >> (8 + z)) & 1u)) continue;   // wave-uniform
+        const unsigned cs = nib[z] | (nib[z + 1] << 4);
+        const bool on = y_live && cs != 0u && cs != 255u;
+        const u64 m = __builtin_amdgcn_ballot_w64(on);
+        if (on) {
+            const int i = n_act + (int)lanes_below(m);
+            acell[i] = (unsigned short)(64 * z + lane);
+            acase[i] = (unsigned char)cs;
         }
-        if (!have_lo) layer_masks(z, any_lo, all_lo);
-        u64 any_hi, all_hi;
-        layer_masks(z + 1, any_hi, all_hi);
-        const u64 act = (any_lo | any_hi) & ~(all_lo & all_hi) & y_live;   // not all eight corners equal, in a live y layer
-        any_lo = any_hi;
-        all_lo = all_hi;
-        have_lo = true;
-        if (__builtin_amdgcn_inverse_ballot_w64(act)) acell[n_act + (int)lanes_below(act)] = (unsigned short)(64 * z + lane);
-        n_act += __builtin_popcountll(act);
+        n_act += __builtin_popcountll(m);
     }
     return n_act;
 }
@@ -307,7 +319,7 @@ __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_v
                                                      int block_id, float *__restrict__ out, int lane, int ablate,
                                                      unsigned rowmask, int &vm_issued)
 {
-    const int n_act = compact_active_cells(L->tile, L->acell, lane, rowmask);   // pass 1
+    const int n_act = compact_active_cells(L->tile, L->acell, L->cases, lane, rowmask);   // pass 1
     VTMC_WAVE_SYNC();
 
     // pass 2: triangle slots, 64 active cells per step
@@ -323,7 +335,7 @@ __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_v
         const int idx = c0 + lane;
         const bool valid = idx < n_act;
         const unsigned cell = valid ? L->acell[idx] : 0u;
-        const u64 vw = valid ? s_vert[cell_case(L->tile, cell)] : 0ull;  // fifteen 4-bit edge ids + the count in the top nibble
+        const u64 vw = valid ? s_vert[L->cases[idx]] : 0ull;  // fifteen 4-bit edge ids + the count in the top nibble
         const unsigned n = (unsigned)(vw >> 60);
         unsigned step_total;
         const unsigned pre_n = wave_prefix3(n, step_total);
@@ -383,15 +395,19 @@ struct OnceTables {
     unsigned short ownx[8];      // which coordinates of a cell are 7 -> the far-face edges it owns
 };
 
-__device__ __forceinline__ unsigned once_edge_entry(unsigned e)
+__host__ __device__ constexpr unsigned once_edge_entry(unsigned e)
 {
     const unsigned g = (unsigned)(kEdgeGeom >> (5u * e)) & 31u;
     const unsigned axis = g >> 3, low = g & 7u & ~(1u << axis);
     const unsigned lx = low & 1u, ly = (low >> 1) & 1u, lz = low >> 2;
     return lx | (ly << 4) | (lz << 8) | (axis << 12) | ((axis * 729u + lx + 9u * ly + 81u * lz) << 16);
 }
+// the cube edges a cell can own, in the order the vertex-once numbering takes them: the three at its corner 0 (x, y, z lattice edges
+// starting there), then the nine far-face edges of a boundary cell (once_ownx_entry).  Every entry is a compile-time constant in the
+// unrolled numbering rounds: no table look-up, no LDS round trip
+constexpr unsigned kOwnedEdgeOrder[12] = {0, 3, 8, 1, 2, 4, 5, 6, 7, 9, 10, 11};
 
-__device__ __forceinline__ unsigned short once_ownx_entry(unsigned b7)
+__host__ __device__ constexpr unsigned short once_ownx_entry(unsigned b7)
 {
     const unsigned X = b7 & 1, Y = (b7 >> 1) & 1, Z = (b7 >> 2) & 1;
     return (unsigned short)((X * 0x202u) | (Y * 0x804u) | (Z * 0x090u) | ((X & Y) * 0x400u) | ((X & Z) * 0x020u) | ((Y & Z) * 0x040u));
@@ -423,23 +439,50 @@ __device__ __forceinline__ void eval_vertex(const float *tile, unsigned d, float
     const int c[3] = {(int)(d & 15u), (int)((d >> 4) & 15u), (int)((d >> 8) & 15u)};
     const unsigned axis = d >> 12;
     const int sk = axis == 0 ? 1 : (axis == 1 ? 10 : 100);
-    const int tl = c[0] + 10 * c[1] + 100 * c[2];
-    const float va = tile[tl], vb = tile[tl + sk];
+    const int tl = c[0] + 10 * c[1] + 100 * c[2], th = tl + sk;
+    // ONE round of LDS reads: the samples at both ends of the edge and their forward neighbours.  t lies in [0, 1], so floor(P) and ceil(P)
+    // (MarchingCube.compute:71-72) are the edge's own endpoints: both lattice gradients (SampleNormal.compute:27-30) are known before t is,
+    // which of them is c0 / c1 is a select afterwards (round 4 computed t first and fetched the gradients behind it: two round trips)
+    const float va = tile[tl], vb = tile[th];
+    float glo[3] = {va - tile[tl + 1], va - tile[tl + 10], va - tile[tl + 100]};
+    float ghi[3] = {vb - tile[th + 1], vb - tile[th + 10], vb - tile[th + 100]};
     // t lies in [0,1] (the endpoints differ in sign class); the 1-ulp v_rcp can land a hair outside: clamp it back
     const float t = FAST ? __builtin_amdgcn_fmed3f(-va * __builtin_amdgcn_rcpf(vb - va), 0.0f, 1.0f) : (-va) / (vb - va);
     const float ckf = (float)(axis == 0 ? c[0] : (axis == 1 ? c[1] : c[2]));
     const float q = ckf + t;
     const float fq = floorf(q);
     const float w = q - fq;   // the weight comes from the ROUNDED position (MarchingCube.compute:71-72)
-    float g0[3], g1[3];
-    lattice_gradient(tile, tl + (int)(fq - ckf) * sk, g0);
-    lattice_gradient(tile, tl + (int)(ceilf(q) - ckf) * sk, g1);
-    normalise<FAST>(g0);
-    normalise<FAST>(g1);
+    const bool c0_hi = (int)(fq - ckf) != 0, c1_hi = (int)(ceilf(q) - ckf) != 0;
+    normalise<FAST>(glo);
+    normalise<FAST>(ghi);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
+        const float g0 = c0_hi ? ghi[a] : glo[a], g1 = c1_hi ? ghi[a] : glo[a];
         rec[a] = axis == (unsigned)a ? q : (float)c[a];
-        rec[3 + a] = FAST ? __builtin_fmaf(w, g1[a] - g0[a], g0[a]) : g0[a] + w * (g1[a] - g0[a]);
+        rec[3 + a] = FAST ? __builtin_fmaf(w, g1 - g0, g0) : g0 + w * (g1 - g0);
+    }
+}
+
+// one triangle of the vertex-once expansion: slot -> three table look-ups (cube edge -> lattice edge -> vertex id) -> three 24-byte records
+__device__ __forceinline__ void once_gather_record(const unsigned *slot, const unsigned char *vtab, const float *verts, const OnceTables *tb, int s,
+                                                   float (&rec)[18])
+{
+    const unsigned sc = slot[s];
+    const unsigned cell = sc & 511u, trip = sc >> 9;
+    const unsigned cell9 = (cell & 7u) + 9u * ((cell >> 3) & 7u) + 81u * (cell >> 6);
+    // table entries (3i, 3i+2, 3i+1): the winding swap of MarchingCube.compute:147-157
+    const unsigned e[3] = {trip & 15u, (trip >> 8) & 15u, (trip >> 4) & 15u};
+    unsigned vid[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vid[k] = vtab[cell9 + (tb->edge[e[k]] >> 16)];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float *v = verts + vid[k] * 6u;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            rec[3 * k + a] = v[a];
+            rec[9 + 3 * k + a] = v[3 + a];
+        }
     }
 }
 
@@ -452,46 +495,37 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
         return;
     }
     const float *tile = L->c.tile;
-    const int n_act = compact_active_cells(tile, L->c.acell, lane, rowmask);   // pass 1
+    const int n_act = compact_active_cells(tile, L->c.acell, L->c.cases, lane, rowmask);   // pass 1
     VTMC_WAVE_SYNC();
     pc.mark(2);
     unsigned short *vlist = L->vlist();
     unsigned char *vtab = L->vtab();
 
-    // N + pass 2, 64 active cells per step: vertex numbering and triangle slots
+    // N + pass 2, 64 active cells per step: vertex numbering and triangle slots.  One LDS round for the cell and its case, one for the
+    // three tables; everything behind them runs on registers and compile-time constants.
     int n_vert = 0, pending = 0;
     for (int c0 = 0; c0 < n_act; c0 += 64) {
         const int idx = c0 + lane;
         const bool valid = idx < n_act;
-        const unsigned cell = valid ? L->c.acell[idx] : 0u;
-        const unsigned cs = valid ? cell_case(tile, cell) : 0u;   // case 0: no edges, no triangles
-        const u64 vw = s_vert[cs];
-        const unsigned em = tb->emask[cs];
+        const int ic = valid ? idx : n_act - 1;
+        const unsigned cell = L->c.acell[ic];
+        const unsigned cs = valid ? (unsigned)L->c.cases[ic] : 0u;   // case 0: no edges, no triangles
         const unsigned cx = cell & 7u, cy = (cell >> 3) & 7u, cz = cell >> 6;
+        const unsigned b7 = (unsigned)(cx == 7u) | ((unsigned)(cy == 7u) << 1) | ((unsigned)(cz == 7u) << 2);
+        const u64 vw = s_vert[cs];
+        const unsigned owned = tb->emask[cs] & (0x109u | tb->ownx[b7]);   // the three edges at corner 0, and the far-face edges of a boundary cell
         const unsigned desc = cx | (cy << 4) | (cz << 8);
         const unsigned cell9 = cx + 9u * cy + 81u * cz;
-        // the three edges at the cell's corner 0 (cube edges 0, 3, 8 = the x, y, z lattice edges starting there): one ballot each
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const bool has = (em >> (a == 0 ? 0 : (a == 1 ? 3 : 8))) & 1u;
+        for (int r = 0; r < 12; ++r) {   // one ballot per cube edge a cell can own; a round nobody needs costs a compare and a branch
+            const unsigned ed = once_edge_entry(kOwnedEdgeOrder[r]);   // folds to an immediate
+            const bool has = ((owned >> kOwnedEdgeOrder[r]) & 1u) != 0u;
             const u64 m = __builtin_amdgcn_ballot_w64(has);
+            if (m == 0ull) continue;   // wave-uniform
             if (has) {
-                const int id = n_vert + (int)lanes_below(m);
-                if (id < kVertCap) vlist[id] = (unsigned short)(desc | ((unsigned)a << 12));
-                vtab[729 * a + cell9] = (unsigned char)id;
-            }
-            n_vert += __builtin_popcountll(m);
-        }
-        // the far-face edges of a boundary cell: each round takes every lane's next one
-        const unsigned b7 = (unsigned)(cx == 7u) | ((unsigned)(cy == 7u) << 1) | ((unsigned)(cz == 7u) << 2);
-        unsigned ex = em & tb->ownx[b7];
-        for (u64 m = __builtin_amdgcn_ballot_w64(ex != 0u); m != 0ull; m = __builtin_amdgcn_ballot_w64(ex != 0u)) {
-            if (ex) {
-                const unsigned ed = tb->edge[__builtin_ctz(ex)];
                 const int id = n_vert + (int)lanes_below(m);
                 if (id < kVertCap) vlist[id] = (unsigned short)(desc + (ed & 0xFFFFu));
                 vtab[cell9 + (ed >> 16)] = (unsigned char)id;
-                ex &= ex - 1u;
             }
             n_vert += __builtin_popcountll(m);
         }
@@ -514,13 +548,13 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
     VTMC_WAVE_SYNC();
     pc.mark(3);
 
-    // V: one lane per vertex, from the edge's low endpoint
+    // V: one lane per vertex, from the edge's low endpoint.  Branch-free up to the store: a lane past the end evaluates the last vertex again
     float *verts = L->verts();
     for (int s0 = 0; s0 < n_vert && !(ablate & 4); s0 += 64) {
         const int s = s0 + lane;
+        float r6[6];
+        eval_vertex<FAST>(tile, vlist[s < n_vert ? s : n_vert - 1], r6);
         if (s < n_vert) {
-            float r6[6];
-            eval_vertex<FAST>(tile, vlist[s], r6);
             float *rec = verts + s * 6;
 #pragma unroll
             for (int a = 0; a < 6; ++a) rec[a] = r6[a];
@@ -529,35 +563,26 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
     VTMC_WAVE_SYNC();
     pc.mark(4);
 
-    // T: one lane per triangle; the staging area lies over the tile, which nobody reads any more
+    // T: one lane per triangle; the staging area lies over the tile, which nobody reads any more.  Two batches of 64 at a time: the
+    // look-up chain of the second (slot -> edge table -> vertex id -> vertex records: four LDS round trips) runs beside the first one's
     float *stage = L->c.tile;
-    for (int s0 = 0; s0 < pending; s0 += 64) {
-        const int s = s0 + lane;
-        float rec[18];
-#pragma unroll
-        for (int k = 0; k < 18; ++k) rec[k] = 0.f;
-        if (s < pending) {
-            const unsigned sc = L->c.slot[s];
-            const unsigned cell = sc & 511u, trip = sc >> 9;
-            const unsigned cell9 = (cell & 7u) + 9u * ((cell >> 3) & 7u) + 81u * (cell >> 6);
-            // table entries (3i, 3i+2, 3i+1): the winding swap of MarchingCube.compute:147-157
-            const unsigned e[3] = {trip & 15u, (trip >> 8) & 15u, (trip >> 4) & 15u};
-            unsigned vid[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) vid[k] = vtab[cell9 + (tb->edge[e[k]] >> 16)];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float *v = verts + vid[k] * 6u;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    rec[3 * k + a] = v[a];
-                    rec[9 + 3 * k + a] = v[3 + a];
-                }
-            }
+    for (int s0 = 0; s0 < pending; s0 += 128) {
+        const int sa = s0 + lane, sb = sa + 64;
+        float ra[18], rb[18];
+        const bool two = s0 + 64 < pending;   // wave-uniform
+        if (two) {   // both chains in one basic block: the scheduler issues their loads side by side
+            once_gather_record(L->c.slot, vtab, verts, tb, sa, ra);
+            once_gather_record(L->c.slot, vtab, verts, tb, sb < pending ? sb : pending - 1, rb);
+        } else {
+            once_gather_record(L->c.slot, vtab, verts, tb, sa < pending ? sa : pending - 1, ra);
         }
-        const int cnt = pending - s0 < 64 ? pending - s0 : 64;
         pc.mark(5);
-        stream_batch76(stage, rec, s < pending, cnt, (tri_base + (size_t)s0) * kTriDwords, block_id, out, lane, ablate, vm_issued);
+        const int na = pending - s0 < 64 ? pending - s0 : 64;
+        stream_batch76(stage, ra, sa < pending, na, (tri_base + (size_t)s0) * kTriDwords, block_id, out, lane, ablate, vm_issued);
+        if (two) {
+            const int nb = pending - s0 - 64 < 64 ? pending - s0 - 64 : 64;
+            stream_batch76(stage, rb, sb < pending, nb, (tri_base + (size_t)s0 + 64) * kTriDwords, block_id, out, lane, ablate, vm_issued);
+        }
         pc.mark(6);
     }
 }
@@ -600,7 +625,7 @@ struct __attribute__((aligned(16))) EmitLdsIdx {
         unsigned char vtab[2192];   // <= 255 vertices: lattice edge (axis * 729 + x + 9 y + 81 z) -> vertex id
         unsigned cellmap[512];      // more: owner cell -> first vertex id | owned-edge mask << 16 (active cells only)
     } m;
-    unsigned char cases[512];       // case of every active cell (numbering -> pass 2)
+    unsigned char cases[512];       // cases[i]: the case of cell acell[i] (pass 1 -> numbering -> pass 2)
 };   // 8240 bytes: with the shared tables a workgroup of THREE waves takes 27 024 bytes -- six per CU, 18 waves (four-wave workgroups: 16)
 static_assert(sizeof(EmitLdsIdx) % 16 == 0, "keeps the waves' blocks 16-byte aligned");
 
@@ -647,7 +672,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
     typedef int i3u __attribute__((ext_vector_type(3), aligned(4)));
     const float *tile = L->t.tile;
     // pass 1: compaction of the active cells (as the soup path, row masks included)
-    const int n_act = compact_active_cells(tile, L->acell, lane, rowmask);
+    const int n_act = compact_active_cells(tile, L->acell, L->cases, lane, rowmask);
     VTMC_WAVE_SYNC();
     const bool big = vert_budget > kIdxFastVerts;   // wave-uniform: the scan's vertex count of this block decides the numbering's form
 
@@ -658,8 +683,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
             const int idx = c0 + lane;
             const bool valid = idx < n_act;
             const unsigned cell = valid ? L->acell[idx] : 0u;
-            const unsigned cs = valid ? cell_case(tile, cell) : 0u;
-            if (first && valid) L->cases[cell] = (unsigned char)cs;   // for pass 2
+            const unsigned cs = valid ? (unsigned)L->cases[idx] : 0u;   // pass 1 left the case beside the cell
             const unsigned cx = cell & 7u, cy = (cell >> 3) & 7u, cz = cell >> 6;
             const unsigned b7 = (unsigned)(cx == 7u) | ((unsigned)(cy == 7u) << 1) | ((unsigned)(cz == 7u) << 2);
             const unsigned owned = valid ? (case_edge_mask(cs) & (0x109u | tb->ownx[b7])) : 0u;
@@ -668,36 +692,22 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
             unsigned step_total;
             const int id0 = vrun + (int)wave_prefix4((unsigned)__builtin_popcount(owned), step_total);
             if (big && first && valid) L->m.cellmap[cell] = (unsigned)id0 | (owned << 16);
-            // the three edges at the cell's corner 0 (cube edges 0, 3, 8): their rank among the cell's owned edges is a popcount
+            // one round per cube edge a cell can own (the three at its corner 0, then the far-face edges of a boundary cell): the edge's
+            // geometry is a compile-time constant, its rank among the cell's owned edges a popcount; a round nobody needs is skipped
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const unsigned bit = a == 0 ? 0u : (a == 1 ? 3u : 8u);
-                if ((owned >> bit) & 1u) {
-                    const int id = id0 + __builtin_popcount(owned & ((1u << bit) - 1u));
-                    if (!big) {   // at most 255 vertices: one window, every id has its byte
-                        L->vlist[id & 255] = (unsigned short)(desc | ((unsigned)a << 12));   // & 255: a count mismatch could never write outside the list
-                        L->m.vtab[729 * a + cell9] = (unsigned char)id;
-                    } else {
-                        const int q = id - window;
-                        if (q >= 0 && q < kVlistCap) L->vlist[q] = (unsigned short)(desc | ((unsigned)a << 12));
-                    }
-                }
-            }
-            // the far-face edges of a boundary cell, each round every lane's next one
-            unsigned ex = owned & ~0x109u;
-            while (__builtin_amdgcn_ballot_w64(ex != 0u)) {
-                if (ex) {
-                    const unsigned e = (unsigned)__builtin_ctz(ex);
-                    const unsigned ed = tb->edge[e];
+            for (int r = 0; r < 12; ++r) {
+                const unsigned e = kOwnedEdgeOrder[r], ed = once_edge_entry(kOwnedEdgeOrder[r]);
+                const bool has = ((owned >> e) & 1u) != 0u;
+                if (r >= 3 && __builtin_amdgcn_ballot_w64(has) == 0ull) continue;   // wave-uniform
+                if (has) {
                     const int id = id0 + __builtin_popcount(owned & ((1u << e) - 1u));
-                    if (!big) {
-                        L->vlist[id & 255] = (unsigned short)(desc + (ed & 0xFFFFu));
+                    if (!big) {   // at most 255 vertices: one window, every id has its byte
+                        L->vlist[id & 255] = (unsigned short)(desc + (ed & 0xFFFFu));   // & 255: a count mismatch could never write outside the list
                         L->m.vtab[cell9 + (ed >> 16)] = (unsigned char)id;
                     } else {
                         const int q = id - window;
                         if (q >= 0 && q < kVlistCap) L->vlist[q] = (unsigned short)(desc + (ed & 0xFFFFu));
                     }
-                    ex &= ex - 1u;
                 }
             }
             vrun += (int)step_total;
@@ -770,7 +780,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
         const int idx = c0 + lane;
         const bool valid = idx < n_act;
         const unsigned cell = valid ? L->acell[idx] : 0u;
-        const u64 vw = valid ? s_vert[(unsigned)L->cases[cell]] : 0ull;   // the tile is gone: the slots lie over it
+        const u64 vw = valid ? s_vert[(unsigned)L->cases[idx]] : 0ull;   // the tile is gone: the slots lie over it
         const unsigned n = (unsigned)(vw >> 60);
         unsigned step_total;
         const unsigned pre_n = wave_prefix3(n, step_total);

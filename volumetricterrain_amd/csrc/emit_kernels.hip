@@ -121,12 +121,12 @@ __device__ __forceinline__ void wait_vm_at_most(int n, float (&t)[20], unsigned 
 template <bool FAST, bool INDEXED, bool ONCE = false, int WAVES = kWavesPerWg>
 __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void emit_kernel(BlockSpace sp, DeviceTables tb,
                                                     const uint32_t *__restrict__ offsets,
-                                                    const int32_t *__restrict__ active_list,
+                                                    const BlockDesc *__restrict__ active,
                                                     const uint32_t *__restrict__ totals, uint32_t capacity,
                                                     float *__restrict__ out, int ablate_arg, unsigned *__restrict__ queue, int sub_log2,
                                                     const uint32_t *__restrict__ voffsets, const uint32_t *__restrict__ vtotals,
                                                     uint32_t vcapacity, int *__restrict__ out_indices,
-                                                    const uint32_t *__restrict__ rowmasks, uint32_t *__restrict__ volume_counts, int n_volumes)
+                                                    int use_row_masks, uint32_t *__restrict__ volume_counts, int n_volumes)
 {
     static_assert(!(ONCE && INDEXED), "ONCE is a form of the soup");
     const int ablate = VTMC_ABLATE(ablate_arg);   // product build: 0, every diagnostic branch below folds away
@@ -244,18 +244,23 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
         struct Blk {
             int b;
             unsigned mask;
-            uint32_t tri_base, tri_end, vert_base, vert_end;
+            uint32_t tri_base, tri_cnt, vert_base, vert_cnt;
+            long long origin;
         };
-        auto describe = [&](int entry) {   // scalar loads only (lgkmcnt): nothing here touches vmcnt
-            Blk d{-1, 0xFFFFu, 0u, 0u, 0u, 0u};
+        auto describe = [&](int entry) {   // ONE 32-byte scalar load (lgkmcnt): the scan left the block's record in list order; nothing here touches vmcnt
+            Blk d{-1, 0xFFFFu, 0u, 0u, 0u, 0u, 0ll};
             if (entry < ai_end) {
-                d.b = active_list[(ablate & 2) ? ai_begin + (entry & 3) : entry];
-                if (rowmasks) d.mask = rowmasks[d.b] >> 16;
-                d.tri_base = offsets[d.b];
-                d.tri_end = offsets[d.b + 1];
+                typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+                typedef const __attribute__((address_space(4))) u32x8 *desc_ptr;   // written by the scan, never during this launch: a scalar load
+                const u32x8 r = *((desc_ptr)active + entry);   // BlockDesc: b, tri_base, cnt_mask, vert_base, origin lo / hi, vert_cnt, pad
+                d.b = (int)r[0];
+                d.mask = use_row_masks ? r[2] >> 16 : 0xFFFFu;
+                d.tri_base = r[1];
+                d.tri_cnt = r[2] & kCountMask;
+                d.origin = (long long)(((unsigned long long)r[5] << 32) | r[4]);
                 if constexpr (INDEXED) {
-                    d.vert_base = voffsets[d.b];
-                    d.vert_end = voffsets[d.b + 1];
+                    d.vert_base = r[3];
+                    d.vert_cnt = r[6];
                 }
             }
             return d;
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
         request_async();
         wait_vm_at_most(0, pre, tick);
         Blk nxt = describe(collect_async());
-        if (cur.b >= 0) load_rows_async(reinterpret_cast<const char *>(sp.base + block_origin(sp, cur.b)), cur.mask, pre);
+        if (cur.b >= 0) load_rows_async(reinterpret_cast<const char *>(sp.base + cur.origin), cur.mask, pre);
         request_async();
         pc.start();
         while (cur.b >= 0) {
@@ -288,14 +293,14 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
             VTMC_WAVE_SYNC();
             store_tile(tile_of(L), pre);
             const int far_entry = collect_async();
-            if (nxt.b >= 0) load_rows_async(reinterpret_cast<const char *>(sp.base + block_origin(sp, nxt.b)), nxt.mask, pre);
+            if (nxt.b >= 0) load_rows_async(reinterpret_cast<const char *>(sp.base + nxt.origin), nxt.mask, pre);
             request_async();
-            const Blk far = describe(far_entry);   // two dependent scalar loads: behind the tile loads, so only the wave's own LDS work waits for them
+            const Blk far = describe(far_entry);   // one scalar load, behind the tile loads: only the wave's own LDS work waits for it
             VTMC_WAVE_SYNC();
             pc.mark(1);
-            const int budget = (int)(cur.tri_end - cur.tri_base);
+            const int budget = (int)cur.tri_cnt;
             if constexpr (INDEXED)
-                emit_block_indexed<FAST>(L, s_vert, s_own, &s_once[0], (size_t)cur.tri_base, budget, (size_t)cur.vert_base, (int)(cur.vert_end - cur.vert_base), out,
+                emit_block_indexed<FAST>(L, s_vert, s_own, &s_once[0], (size_t)cur.tri_base, budget, (size_t)cur.vert_base, (int)cur.vert_cnt, out,
                                          out_indices, lane, ablate, cur.mask, vm_issued);
             else if constexpr (ONCE)
                 emit_block_once<FAST>(L, s_vert, &s_once[0], (size_t)cur.tri_base, budget, cur.b, out, lane, ablate, cur.mask, vm_issued, pc);
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
 }
 
 hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets,
-                       const int32_t *active_list, const uint32_t *totals, const uint32_t *counts_or_null, uint32_t capacity,
+                       const BlockDesc *active, const uint32_t *totals, uint32_t capacity,
                        void *triangles, int n_cus, const Tuning &tune, unsigned *queue, uint32_t *volume_counts, int n_volumes,
                        hipStream_t stream)
 {
@@ -329,7 +334,7 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
     float *o = (float *)triangles;
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
     launch_begin();
-#define VTMC_LAUNCH_SOUP(F, O) hipLaunchKernelGGL((emit_kernel<F, false, O>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, capacity, o, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes)
+#define VTMC_LAUNCH_SOUP(F, O) hipLaunchKernelGGL((emit_kernel<F, false, O>), g, blk, 0, stream, sp, tb, offsets, active, totals, capacity, o, tune.emit_ablate, q, tune.emit_sub_log2, nullptr, nullptr, 0u, nullptr, tune.emit_row_masks, volume_counts, n_volumes)
     if (once) VTMC_LAUNCH_SOUP(true, true);
     else if (tune.emit_fast_math) VTMC_LAUNCH_SOUP(true, false);
     else VTMC_LAUNCH_SOUP(false, false);
@@ -338,7 +343,7 @@ hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint3
 }
 
 hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets, const uint32_t *voffsets,
-                               const int32_t *active_list, const uint32_t *totals, const uint32_t *vtotals, const uint32_t *counts_or_null,
+                               const BlockDesc *active, const uint32_t *totals, const uint32_t *vtotals,
                                uint32_t tri_capacity,
                                uint32_t vert_capacity, void *vertices, void *indices, int n_cus, const Tuning &tune, unsigned *queue,
                                uint32_t *volume_counts, int n_volumes, hipStream_t stream)
@@ -351,7 +356,7 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
     dim3 g(wgs), blk(three ? 192 : 256);
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
     launch_begin();
-#define VTMC_LAUNCH_IDX(F, W) hipLaunchKernelGGL((emit_kernel<F, true, false, W>), g, blk, 0, stream, sp, tb, offsets, active_list, totals, tri_capacity, (float *)vertices, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, tune.emit_row_masks ? counts_or_null : nullptr, volume_counts, n_volumes)
+#define VTMC_LAUNCH_IDX(F, W) hipLaunchKernelGGL((emit_kernel<F, true, false, W>), g, blk, 0, stream, sp, tb, offsets, active, totals, tri_capacity, (float *)vertices, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, tune.emit_row_masks, volume_counts, n_volumes)
     if (three) {
         if (tune.emit_fast_math) VTMC_LAUNCH_IDX(true, 3);
         else VTMC_LAUNCH_IDX(false, 3);

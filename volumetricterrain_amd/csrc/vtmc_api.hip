@@ -100,12 +100,12 @@ int queue_emit(vtmc_ctx *ctx, bool retry)
     if (ctx->comm && pe.counts_early && ctx->tune.gather_beside) tune.emit_spare_wgs = 8;   // vtmc_allgather_volume_counts runs its kernel beside this one
     if (indexed)
         VTMC_HIP(ctx, launch_emit_indexed(pe.sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const uint32_t *)ctx->voffsets.p,
-                                          (const int32_t *)ctx->active.p, (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->vtotals.p,
-                                          (const uint32_t *)ctx->counts.p, (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p, ctx->indices.p, ctx->n_cus,
+                                          (const BlockDesc *)ctx->active.p, (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->vtotals.p,
+                                          (uint32_t)tcap, (uint32_t)vcap, ctx->verts.p, ctx->indices.p, ctx->n_cus,
                                           tune, queue, vc, pe.n_volumes, stream));
     else
-        VTMC_HIP(ctx, launch_emit(pe.sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const int32_t *)ctx->active.p,
-                                  (const uint32_t *)ctx->totals.p, (const uint32_t *)ctx->counts.p, (uint32_t)tcap, ctx->tris.p,
+        VTMC_HIP(ctx, launch_emit(pe.sp, ctx->tables, (const uint32_t *)ctx->offsets.p, (const BlockDesc *)ctx->active.p,
+                                  (const uint32_t *)ctx->totals.p, (uint32_t)tcap, ctx->tris.p,
                                   ctx->n_cus, tune, queue, vc, pe.n_volumes, stream));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
     return VTMC_OK;
@@ -144,7 +144,7 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     if (!indexed && !ctx->tris.p)
         if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * ((size_t)1 << 20))) return rc;
     if (int rc = ensure(ctx, ctx->counts, sizeof(uint32_t) * (size_t)B)) return rc;
-    if (int rc = ensure(ctx, ctx->active, sizeof(int32_t) * (size_t)B)) return rc;
+    if (int rc = ensure(ctx, ctx->active, sizeof(BlockDesc) * (size_t)B)) return rc;   // one record per non-empty block, written by the scan
     if (B >= (1 << 30)) return fail(ctx, VTMC_ERR_TOO_LARGE, "more than 2^30 blocks in one batch");   // the scan's status word holds 30 bits of non-empty blocks
     const size_t ctrl_words = scan_ctrl_words(B);
     if (int rc = ensure(ctx, ctx->partials, sizeof(unsigned long long) * 2 * ctrl_words)) return rc;   // ticket, error word, one or two status words per tile
@@ -191,7 +191,7 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     // one launch: offsets, active list, totals (also straight into the host's pinned words), emit queue cleared; the indexed
     // output's vertex counts ride along, and so do the per-volume counts when every volume is a whole number of scan tiles
     pe.counts_early = n_volumes > 0 && scan_writes_volume_counts(sp.bpv) && (long long)sp.bpv * n_volumes == (long long)B;
-    VTMC_HIP(ctx, launch_scan_fused((const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p, (int32_t *)ctx->active.p, ctrl,
+    VTMC_HIP(ctx, launch_scan_fused(sp, (const uint32_t *)ctx->counts.p, B, (uint32_t *)ctx->offsets.p, (BlockDesc *)ctx->active.p, ctrl,
                                     (uint32_t *)ctx->totals.p, ctx->h_totals_dev, (uint32_t *)ctx->totals.p + 64, kQueueWords, d_vcounts,
                                     indexed ? (uint32_t *)ctx->voffsets.p : nullptr, indexed ? (uint32_t *)ctx->vtotals.p : nullptr,
                                     pe.counts_early ? (uint32_t *)ctx->volcounts.p : nullptr, sp.bpv, stream));
@@ -767,8 +767,11 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     if (k == "emit_row_masks") return ranged(ctx->tune.emit_row_masks, 0, 1);
     if (k == "emit_wgs_per_cu") return ranged(ctx->tune.emit_wgs_per_cu, 0, 8);
     if (k == "emit_idx_waves") return ranged(ctx->tune.emit_idx_waves, 3, 4);
+    // residency caps work by unused dynamic LDS; ONE workgroup per CU would ask for the whole 160 KB, which the runtime answers with abort(): refused
+    if ((k == "classify_wgs_per_cu" || k == "density_wgs_per_cu") && value == 1)
+        return fail(ctx, VTMC_ERR_INVALID_ARG, "tuning key '%s': a cap of one workgroup per CU is not supported (0: none, or 2 and more)", key);
     if (k == "classify_wgs_per_cu") return ranged(ctx->tune.classify_wgs_per_cu, 0, 7);
-    if (k == "density_wgs_per_cu") return ranged(ctx->tune.density_wgs_per_cu, 0, 8);
+    if (k == "density_wgs_per_cu") return ranged(ctx->tune.density_wgs_per_cu, 0, 3);
     if (k == "gather_beside") return ranged(ctx->tune.gather_beside, 0, 1);
     if (k == "stage_events") return ranged(ctx->tune.stage_events, 0, 1);
     if (k == "invalidate_signs") {   // the caller wrote to (or re-used the address of) a buffer the last fill left sign bits for

@@ -45,6 +45,19 @@ struct BlockSpace {
     FastDiv d_bpv, d_nbx, d_nby;
 };
 
+// What the emit kernel needs to know about a non-empty block, written by the scan in list order: ONE 32-byte scalar load per block instead
+// of a chain of four (list entry -> row mask, two offsets) plus the block-id arithmetic.
+struct __attribute__((aligned(32))) BlockDesc {
+    uint32_t b;          // block id (the record's `block` field, VoxelTerrain.cs:35)
+    uint32_t tri_base;   // first triangle of the block in the output
+    uint32_t cnt_mask;   // triangles (<= 2560) | row mask << 16 (counts[b] as the classify pass left it)
+    uint32_t vert_base;  // indexed output: first welded vertex
+    long long origin;    // element offset of the block's 10^3 tile from BlockSpace::base
+    uint32_t vert_cnt;   // indexed output: welded vertices
+    uint32_t pad;
+};
+static_assert(sizeof(BlockDesc) == 32, "one s_load_dwordx8");
+
 struct DeviceTables {
     const unsigned long long *vert_packed;  // 256 x u64 (mc_tables_packed.h)
     const unsigned char *tri_num;           // 256 x u8
@@ -117,19 +130,19 @@ hipError_t launch_classify_dense(const BlockSpace &sp, const DeviceTables &tb, u
 // zero_words / n_zero: 32-bit words to clear on the way (the emit kernel's ticket queue)
 // vcounts_or_null != null: the welded-vertex counts are scanned in the same launch (voffsets, vtotals[0..3] = {V saturating, 0, V lo, V hi},
 // host_totals[4..7]); ctrl then holds 2 * scan_ctrl_words(n_blocks) zeroed words
-hipError_t launch_scan_fused(const uint32_t *counts, int n_blocks, uint32_t *offsets, int32_t *active_list, unsigned long long *ctrl,
+hipError_t launch_scan_fused(const BlockSpace &sp, const uint32_t *counts, int n_blocks, uint32_t *offsets, BlockDesc *active, unsigned long long *ctrl,
                              uint32_t *totals, uint32_t *host_totals, uint32_t *zero_words, int n_zero, const uint32_t *vcounts_or_null,
                              uint32_t *voffsets, uint32_t *vtotals, uint32_t *volume_counts_or_null, int bpv, hipStream_t stream);
 // the scan itself leaves the per-volume counts when a volume is a whole number of scan tiles (else the emit kernel's prologue does)
 inline bool scan_writes_volume_counts(int bpv) { return bpv > 0 && bpv % 2048 == 0; }
 inline size_t scan_ctrl_words(int n_blocks) { return 2 + (size_t)((n_blocks + 2047) / 2048); }
 hipError_t launch_emit(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets,
-                       const int32_t *active_list, const uint32_t *totals, const uint32_t *counts_or_null, uint32_t capacity,
+                       const BlockDesc *active, const uint32_t *totals, uint32_t capacity,
                        void *triangles, int n_cus, const Tuning &tune, unsigned *queue, uint32_t *volume_counts, int n_volumes,
                        hipStream_t stream);   // volume_counts != null: the first workgroup also derives the per-volume counts from the offsets
 
 hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, const uint32_t *offsets, const uint32_t *voffsets,
-                               const int32_t *active_list, const uint32_t *totals, const uint32_t *vtotals, const uint32_t *counts_or_null,
+                               const BlockDesc *active, const uint32_t *totals, const uint32_t *vtotals,
                                uint32_t tri_capacity,
                                uint32_t vert_capacity, void *vertices, void *indices, int n_cus, const Tuning &tune, unsigned *queue,
                                uint32_t *volume_counts, int n_volumes, hipStream_t stream);
