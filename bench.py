@@ -694,19 +694,41 @@ def self_launch(args):
     (exactly the command the task statement gives) before this process has touched the GPU or imported torch, hand its stdout
     through (rank 0's JSON line) and exit with its code.  A process that initialised the GPU is never replaced (no exec), and a
     line with n_gpus = 1 is never printed for a run that asked for N."""
-    import socket
+    import signal
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env["VTMC_BENCH_SELF_LAUNCHED"] = "1"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun picks a free rendezvous port itself (no bind-then-close window another process could take)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node",
+           str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     print("bench.py: --gpus %d without a launcher: starting %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
     sys.stderr.flush()
-    return subprocess.call(cmd, env=env)
+    # the launcher and its ranks in a process group of their own; a SIGTERM / SIGINT to this process is forwarded to the whole group, so a
+    # killed bench never leaves ranks behind holding the GPUs
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+
+    def forward(signum, _frame):
+        try:
+            os.killpg(child.pid, signum)
+        except ProcessLookupError:
+            pass
+
+    old = {sig: signal.signal(sig, forward) for sig in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        while True:
+            try:
+                return child.wait()
+            except KeyboardInterrupt:   # the handler above has already forwarded it
+                continue
+    finally:
+        for sig, h in old.items():
+            signal.signal(sig, h)
+        if child.poll() is None:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
 
 
 def main():

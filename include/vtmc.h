@@ -168,7 +168,7 @@ int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4]);
  * once and the 76-byte records are expanded from LDS; 0: per triangle corner), "emit_dynamic" (default 1: per-XCD ticket counters; 0: a
  * static round-robin over the list of non-empty blocks), "emit_sub_log2" (0-4, default 1: 2^s ticket counters per XCD),
  * "emit_row_masks" (default 1: only tile rows next to cells with triangles are fetched), "emit_wgs_per_cu" (0-8; 0, default: the
- * kernel's own residency), "emit_idx_waves" (indexed output: 4, default: four emit workgroups of four waves per CU; 3: six of three),
+ * kernel's own residency),
  * "classify_wgs_per_cu" (0 or 2-7, default 3: residency cap of the streaming classify kernel; 0: none), "density_wgs_per_cu" (0, 2 or 3:
  * residency cap of the synthetic sampler), "stage_events" (default 1: HIP events between the three kernels for vtmc_last_stage_ms; 0: only around
  * the step), "gather_beside" (default 0: the all-gather of a queued extract runs behind the emit kernel on the caller's stream; 1: beside

@@ -37,3 +37,29 @@ def test_a_launcher_world_of_another_size_is_refused():
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--grid", "256"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "refusing" in p.stderr
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_a_killed_parent_takes_its_launcher_and_ranks_with_it():
+    """SIGTERM to `python bench.py --gpus 2` (no launcher around it) is forwarded to the child launcher's process group: nothing of the
+    run is left behind holding GPUs (advisor, round 4)."""
+    import signal
+    import time
+
+    import psutil
+    parent = subprocess.Popen([sys.executable, "bench.py", "--gpus", "2", "--grid", "256", "--steps", "1", "--warmup", "1"], cwd=ROOT, env=_clean_env(),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    kids = []
+    for _ in range(200):    # until the child launcher exists
+        try:
+            kids = psutil.Process(parent.pid).children(recursive=True)
+        except psutil.NoSuchProcess:
+            break
+        if kids or parent.poll() is not None:
+            break
+        time.sleep(0.05)
+    assert kids, "the child launcher never appeared"
+    parent.send_signal(signal.SIGTERM)
+    parent.wait(timeout=60)
+    assert parent.returncode != 0
+    gone, alive = psutil.wait_procs(kids, timeout=30)
+    assert not alive, "left behind: %r" % alive

@@ -135,21 +135,3 @@ def test_gpu_indexed_all_256_cases_and_tiles(ex, oracle_mod):
     assert np.array_equal(back["block"], soup["block"])
     for f in FLOATS:
         assert np.abs(back[f] - soup[f]).max() <= ATOL
-
-
-@pytest.mark.gpu
-def test_gpu_indexed_three_wave_workgroups(ex, oracle_mod):
-    """Tuning key emit_idx_waves = 3 (six emit workgroups of three waves per CU instead of four of four; the owner table of the
-    > 255-vertex path is computed instead of kept in LDS): the same mesh, against the oracle -- smooth field, noise (blocks of more than
-    255 vertices) and both arithmetic modes."""
-    try:
-        ex.set_output_mode(True)
-        ex.set_tuning(emit_idx_waves=3)
-        check_against_oracle(ex, oracle_mod, oracle_mod.density_volume("perlin3d", 64))
-        g = fields.random_field((72, 24, 16), seed=5)
-        check_against_oracle(ex, oracle_mod, g)
-        ex.set_tuning(emit_fast_math=0)
-        check_against_oracle(ex, oracle_mod, g, exact_floats=True)
-    finally:
-        ex.set_tuning(emit_idx_waves=4, emit_fast_math=1)
-        ex.set_output_mode(False)

@@ -16,7 +16,7 @@ from test_gpu_parity import assert_tris_match
 
 pytestmark = pytest.mark.gpu
 
-DEFAULTS = dict(emit_fast_math=1, emit_once=1, emit_dynamic=1, emit_sub_log2=1, emit_row_masks=1, emit_wgs_per_cu=0, emit_idx_waves=4,
+DEFAULTS = dict(emit_fast_math=1, emit_once=1, emit_dynamic=1, emit_sub_log2=1, emit_row_masks=1, emit_wgs_per_cu=0,
                 classify_wgs_per_cu=3, stage_events=1, gather_beside=0, fill_keeps_signs=0, density_wgs_per_cu=0)
 
 # (tuning, runs in soup mode, runs in indexed mode)
@@ -36,9 +36,7 @@ SETS = [
     (dict(emit_wgs_per_cu=2), True, True),
     (dict(emit_wgs_per_cu=3, emit_once=0), True, False),
     (dict(emit_wgs_per_cu=8), True, True),          # more than fit: the launch still covers the list
-    (dict(emit_idx_waves=3), False, True),
-    (dict(emit_idx_waves=3, emit_fast_math=0), False, True),
-    (dict(emit_idx_waves=3, emit_dynamic=0, emit_row_masks=0), False, True),
+    (dict(emit_dynamic=0, emit_row_masks=0), False, True),
     (dict(classify_wgs_per_cu=0), True, True),
     (dict(classify_wgs_per_cu=2), True, True),
     (dict(classify_wgs_per_cu=4), True, False),
@@ -63,7 +61,10 @@ def cases(oracle_mod):
     out = []
     perlin = oracle_mod.density_volume("perlin3d", 64)
     dense = fields.random_field((40, 16, 24), seed=5)      # 40 cells along x: a partial 64-lane segment; blocks of ~1300 triangles
-    for name, g in (("perlin64", perlin), ("random40x16x24", dense)):
+    wide_x = fields.random_field((200, 16, 8), seed=9, scale=1.0)        # 200 cells along x: three 64-cell segments of the streaming classify + a partial one
+    wide_z = fields.random_field((16, 8, 136), seed=10, order="z")         # the C# z-fastest order, 136 cells along z
+    smooth = oracle_mod.density_volume("perlin3d", 1024, origin=(300, 40, 900), dims=(258, 18, 10))   # 256 cells along x, mostly empty bricks
+    for name, g in (("perlin64", perlin), ("random40x16x24", dense), ("random200x16x8", wide_x), ("random16x8x136_zfast", wide_z), ("perlin256x16x8", smooth)):
         soup, offs, _ = oracle_mod.extract_grid(g, threads=8)
         out.append(dict(name=name, grid=g, tiles=None, soup=soup, offs=offs, indexed=oracle_mod.extract_grid_indexed(g)))
     assert np.diff(out[1]["offs"]).max() > 384 and np.diff(out[1]["indexed"][2]).max() > 255
@@ -132,12 +133,12 @@ def test_sampler_residency_cap_matches_cpu_twin(ex, oracle_mod):
 
 
 def test_refused_keys_and_values(ex):
-    """Keys whose code left the product (one_pass*, emit_async, emit_group_log2), the diagnostic *_ablate keys and values outside a
+    """Keys whose code left the product (one_pass*, emit_async, emit_group_log2, emit_idx_waves), the diagnostic *_ablate keys and values outside a
     key's range answer VTMC_ERR_INVALID_ARG and change nothing."""
     import volumetricterrain_amd as vt
     for key, value in (("one_pass", 1), ("one_pass_depth", 2), ("one_pass_unit", 1), ("one_pass_prefetch", 1), ("emit_async", 0),
                        ("emit_group_log2", 2), ("emit_ablate", 1), ("classify_ablate", 1), ("density_ablate", 1), ("no_such_key", 0),
-                       ("emit_idx_waves", 5), ("emit_idx_waves", 2), ("emit_sub_log2", 5), ("emit_sub_log2", -1), ("emit_wgs_per_cu", 9),
+                       ("emit_idx_waves", 3), ("emit_idx_waves", 4), ("classify_wide", 1), ("emit_sub_log2", 5), ("emit_sub_log2", -1), ("emit_wgs_per_cu", 9),
                        ("classify_wgs_per_cu", 8), ("classify_wgs_per_cu", 1), ("density_wgs_per_cu", 1), ("density_wgs_per_cu", 4), ("emit_fast_math", 2), ("emit_once", -1)):
         with pytest.raises(vt.VtmcError) as e:
             ex.set_tuning(**{key: value})

@@ -36,7 +36,7 @@ def main():
     d = torch.empty(len(origins) * dim ** 3, dtype=torch.float32, device="cuda")
     ex.density_fill_device(vt.density_params(args.kind, n), origins, (dim, dim, dim), (1, dim, dim * dim), dim ** 3,
                            d.data_ptr())
-    defaults = dict(emit_fast_math=1, emit_wgs_per_cu=0, emit_dynamic=1, emit_sub_log2=1, indexed=0, emit_row_masks=1, classify_wgs_per_cu=3, stage_events=1, emit_idx_waves=4, emit_once=1)
+    defaults = dict(emit_fast_math=1, emit_wgs_per_cu=0, emit_dynamic=1, emit_sub_log2=1, indexed=0, emit_row_masks=1, classify_wgs_per_cu=3, stage_events=1, emit_once=1)
     if os.environ.get("VTMC_LIB", "").endswith(("_diag.so", "_phases.so", "_timeline.so")):   # -DVTMC_DIAGNOSTICS builds know the ablation keys
         defaults.update(emit_ablate=0, classify_ablate=0)
 

@@ -185,19 +185,22 @@ def counted_stores(name, lines):
     n3 = sum(1 for c in body if c.startswith("global_store_dwordx3"))
     n2 = sum(1 for c in body if c.startswith("global_store_dwordx2"))
     problems = []
-    indexed = False
+    indexed = once = False
     if "emit_kernel" in name:
-        # template arguments in order: FAST, INDEXED, ASYNC, ONCE, WAVES
+        # template arguments in order: FAST, INDEXED, ONCE
         args = re.findall(r"Lb([01])E", name)
         indexed = len(args) >= 2 and args[1] == "1"
+        once = len(args) >= 3 and args[2] == "1"
     if indexed:
         if n3 < 3:
             problems.append("%s: %d global_store_dwordx3 (the source counts 2 vertex stores + 1 index store per batch)" % (name[:60], n3))
         if n4 or n2:
             problems.append("%s: unexpected store widths in the indexed kernel (dwordx4 %d, dwordx2 %d)" % (name[:60], n4, n2))
     else:
-        if n4 < 3 or n4 % 3:
-            problems.append("%s: %d global_store_dwordx4 (the source counts the three unrolled passes of stream_out_range per call)" % (name[:60], n4))
+        # per inlined call: three passes (stream_batch76, half a batch at a time) or, in the vertex-once kernel, five (stream_batch76_full)
+        ok = n4 >= 3 and (any((n4 - 5 * k) >= 0 and (n4 - 5 * k) % 3 == 0 for k in range(1, n4 // 5 + 1)) if once else n4 % 3 == 0)
+        if not ok:
+            problems.append("%s: %d global_store_dwordx4 (the source counts three -- vertex-once: five -- unrolled passes of stream_out_range per call)" % (name[:60], n4))
         if n3 or n2:
             problems.append("%s: unexpected store widths in the soup kernel (dwordx3 %d, dwordx2 %d)" % (name[:60], n3, n2))
     return problems

@@ -81,12 +81,15 @@ class VtmcError(RuntimeError):
 _lib = None
 
 
-def load():
-    """Load (building if stale) libvtmc.so and declare the prototypes."""
+def load(path=None):
+    """Load (building if stale) libvtmc.so and declare the prototypes.  `path`: another build of the library, loaded beside the product's
+    and not cached (tools/ab_two_libs.py: two builds alternating in ONE process -- boxes of the pool drift by several percent between
+    processes)."""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
-    path = os.environ.get("VTMC_LIB") or _build.build()   # VTMC_LIB: A/B of two builds on one box (tools/ab_bench.py)
+    explicit = path is not None
+    path = path or os.environ.get("VTMC_LIB") or _build.build()   # VTMC_LIB: A/B of two builds on one box (tools/ab_bench.py)
     # PyTorch wheels bundle their own libamdhip64; if this process is going to use torch as well
     # (device memory, streams, torch.distributed), torch must load first so both bind to ONE HIP
     # runtime -- loaded the other way round torch.cuda reports no device.
@@ -143,7 +146,8 @@ def load():
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int:
             fn.restype = i32
-    _lib = L
+    if not explicit:
+        _lib = L
     return L
 
 

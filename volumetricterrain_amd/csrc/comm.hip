@@ -248,9 +248,13 @@ int32_t vtmc_allgather_volume_counts(vtmc_ctx *ctx, uint32_t *d_all_counts, int3
     }
     VTMC_NCCL(ctx, a, a.AllGather(send, d_all_counts, words, ncclUint32, (ncclComm_t)ctx->comm, gs));
     // behind the collective, on whatever stream it went to: comm_release waits for this before the communicator is destroyed
+    // (one event remembers ONE stream: when this collective went to another stream than the one before it, the earlier one is waited for
+    // first -- a communicator must never be destroyed under a collective still queued on a stream the library does not own)
     if (!ctx->ev_last_gather) VTMC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_last_gather, hipEventDisableTiming));
+    if (ctx->gather_recorded && ctx->last_gather_stream != gs) VTMC_HIP(ctx, hipEventSynchronize(ctx->ev_last_gather));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev_last_gather, gs));
     ctx->gather_recorded = true;
+    ctx->last_gather_stream = gs;
     if (beside) {
         VTMC_HIP(ctx, hipEventRecord(ctx->ev_gather, gs));
         VTMC_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_gather, 0));

@@ -43,6 +43,7 @@ struct PhaseClock {
 // ----------------------------------------------------------------------------------------------
 constexpr int kSlotCap = 384;  // triangle slots kept before a flush (a step adds at most 320)
 constexpr int kStageTris = 33; // records staged at a time: half a batch + 1 -- 9.6 KB of LDS per wave, four workgroups per CU
+constexpr int kOnceStageDwords = 64 * kTriDwords + 4;   // vertex-once kernel: a whole batch of 64 records + the alignment shift
 
 struct __attribute__((aligned(16))) EmitLds2 {
     float tile[1000];
@@ -52,6 +53,18 @@ struct __attribute__((aligned(16))) EmitLds2 {
     float stage[kStageTris * kTriDwords + 4];
 };
 static_assert(sizeof(EmitLds2) % 16 == 0 && offsetof(EmitLds2, stage) % 16 == 0, "stage must stay 16-byte aligned");
+
+// What the per-corner path works on: its own LDS block (EmitLds2) or the corresponding areas of the vertex-once kernel's, whose
+// blocks with too many vertices / triangles take this path (EmitLdsOnce::corner_view).
+struct CornerView {
+    float *tile;
+    unsigned *slot;
+    int slot_cap;            // >= 320 + 1: a step of 64 cells adds at most 320 slots
+    unsigned short *acell;
+    unsigned char *cases;
+    float *stage;            // kStageTris records + 4 dwords, 16-byte aligned, NOT over the tile (the flush reads the tile)
+};
+__device__ __forceinline__ CornerView corner_view(EmitLds2 *L) { return CornerView{L->tile, L->slot, kSlotCap, L->acell, L->cases, L->stage}; }
 
 // Edge geometry, 5 bits per edge: offset of endpoint a (x | y << 1 | z << 2) | axis << 3
 // (corner offsets MarchingCube.compute:46-50, edge endpoints MarchingCube.compute:40-43).
@@ -171,6 +184,7 @@ __device__ __forceinline__ void stream_out_range(const float *stage, float *__re
 __device__ __forceinline__ void stream_batch76(float *stage, const float (&rec)[18], bool on, int cnt, size_t d0, int block_id,
                                                float *__restrict__ out, int lane, int ablate, int &vm_issued)
 {
+    if (ablate & 64) d0 &= (size_t)0x7FFFFFu;   // diagnostics: every record lands in the buffer's first 32 MB (stores issued as shipped, nothing reaches the HBM)
     const int sh = (int)(d0 & 3);   // staging shift = global misalignment
     float *gal = out + (d0 - sh);   // 16-byte aligned
     const int split = 32 * kTriDwords + (sh ? 4 : 0);   // multiple of 4
@@ -193,12 +207,32 @@ __device__ __forceinline__ void stream_batch76(float *stage, const float (&rec)[
     VTMC_WAVE_SYNC();
 }
 
+// The 64 records of a batch through a staging area that holds all of them: one round (stage, one wave sync, five unrolled passes of
+// 16-byte stores) instead of the two of stream_batch76.
+__device__ __forceinline__ void stream_batch76_full(float *stage, const float (&rec)[18], bool on, int cnt, size_t d0, int block_id,
+                                                    float *__restrict__ out, int lane, int ablate, int &vm_issued)
+{
+    if (ablate & 64) d0 &= (size_t)0x7FFFFFu;   // diagnostics: every record lands in the buffer's first 32 MB
+    const int sh = (int)(d0 & 3);   // staging shift = global misalignment
+    float *gal = out + (d0 - sh);   // 16-byte aligned
+    VTMC_WAVE_SYNC();
+    if (on) {
+        float *dstrec = stage + sh + lane * kTriDwords;
+#pragma unroll
+        for (int c = 0; c < 18; ++c) dstrec[c] = rec[c];
+        dstrec[18] = __int_as_float(block_id);
+    }
+    VTMC_WAVE_SYNC();
+    stream_out_range<5>(stage, gal, sh, sh + cnt * kTriDwords, lane, ablate, vm_issued, (kOnceStageDwords - 4) & ~3);
+    VTMC_WAVE_SYNC();
+}
+
 // One lane per triangle.  Vertex = position along the edge (MarchingCube.compute:128-133: t =
 // -cube[a] / (cube[b] - cube[a]), lerp with v-u = +-1 on the edge axis and 0 on the others) and the
 // trilinear normal fetch of MarchingCube.compute:69-99, which on a lattice edge is a 2-point lerp
 // whose weight comes from the ROUNDED position (c0 = floor(P), c1 = ceil(P), t = P - c0).
 template <bool FAST>
-__device__ __forceinline__ void emit_flush2(EmitLds2 *L, int pending, size_t tri_base, int block_id,
+__device__ __forceinline__ void emit_flush2(const CornerView &L, int pending, size_t tri_base, int block_id,
                                             float *__restrict__ out, int lane, int ablate, int &vm_issued)
 {
     VTMC_WAVE_SYNC();
@@ -209,14 +243,14 @@ __device__ __forceinline__ void emit_flush2(EmitLds2 *L, int pending, size_t tri
 #pragma unroll
         for (int c = 0; c < 18; ++c) rec[c] = 0.f;
         if (s < pending && !(ablate & 4)) {
-            const unsigned sc = L->slot[s];
+            const unsigned sc = L.slot[s];
             const int cell = sc & 511u;
             const unsigned trip = sc >> 9;
             const int cx = cell & 7, cy = (cell >> 3) & 7, cz = cell >> 6;
             const int tcell = cx + 10 * cy + 100 * cz;
             // table entries (3i, 3i+2, 3i+1): the winding swap of MarchingCube.compute:147-157
             const unsigned e[3] = {trip & 15u, (trip >> 8) & 15u, (trip >> 4) & 15u};
-            const float *tile = L->tile;
+            const float *tile = L.tile;
             EdgeSite es[3];
             float va[3], vb[3], ga[3][3], gb[3][3];
             // One round of LDS reads per vertex: the samples at both endpoints of the edge and their forward neighbours.  t lies in [0, 1], so
@@ -255,7 +289,7 @@ __device__ __forceinline__ void emit_flush2(EmitLds2 *L, int pending, size_t tri
             }
         }
         const int cnt = pending - s0 < 64 ? pending - s0 : 64;
-        stream_batch76(L->stage, rec, s < pending && !(ablate & 4), cnt, d0, block_id, out, lane, ablate, vm_issued);
+        stream_batch76(L.stage, rec, s < pending && !(ablate & 4), cnt, d0, block_id, out, lane, ablate, vm_issued);
     }
 }
 
@@ -266,14 +300,29 @@ __device__ __forceinline__ unsigned cell_case(const float *tile, unsigned cell)
     return layer_nibble(tile, t2, cz) | (layer_nibble(tile, t2, cz + 1) << 4);
 }
 
-// Pass 1 of a block: compaction of the cells that hold triangles, ascending cell id, with their cases.  A lane owns the cell column
-// (x, y) = (lane & 7, lane >> 3).  All 36 samples under the column's nine layers are read UP FRONT (18 ds_read2_b32 behind one
-// another, one wait: round 4's form read a layer, waited, compared, read the next -- 18 LDS round trips in a row, 2 400 cycles per
-// block); the lane keeps the four sign bits of every sample layer as a nibble (strict '>' as CollectTriNum.compute:50; NaN => outside),
-// a cell's case is two nibbles (CollectTriNum.compute:27-51), "has triangles" is case != 0x00 and != 0xFF, and one ballot per cell
-// layer compacts the cells -- each leaves its id and its case, so that no later pass reads the eight corners again.
-// rowmask bits 0-7 / 8-15: the y / z layers that hold such cells (0xFFFF = unknown): only rows next to them were fetched (the others
-// hold stale values), a dead z layer is skipped as a whole (wave-uniform).
+// The four sign bits of a sample layer under a cell column as a nibble, corners 0, 1, 2, 3 of CollectTriNum.compute:27-31 (strict '>' as
+// CollectTriNum.compute:50; NaN => outside).  The emit kernels are bound by ISSUED instructions (a SIMD retires one per four cycles whatever
+// its kind: profiles/r05/emit_issue_bound.txt), and what hipcc makes of `(a > 0) | (b > 0) << 1 | ...` is four v_cmp + four v_cndmask + two
+// v_or + up to four s_nop (gfx950 wants two wait states between a vector compare and a vector read of its mask).  Here: four compares in a
+// row (each mask is two instructions old when it is read), then the bits are shifted in by add-with-carry -- n = 2 n + bit -- eight
+// instructions, no wait states.
+__device__ __forceinline__ unsigned sign_nibble(float c0, float c1, float c2, float c3)
+{
+    unsigned n;
+    unsigned long long m0, m1, m2, m3, dump;
+    asm("v_cmp_lt_f32 %[m3], 0, %[c3]\n\t"
+        "v_cmp_lt_f32 %[m2], 0, %[c2]\n\t"
+        "v_cmp_lt_f32 %[m1], 0, %[c1]\n\t"
+        "v_cmp_lt_f32 %[m0], 0, %[c0]\n\t"
+        "v_addc_co_u32 %[n], %[dump], 0, 0, %[m3]\n\t"
+        "v_addc_co_u32 %[n], %[dump], %[n], %[n], %[m2]\n\t"
+        "v_addc_co_u32 %[n], %[dump], %[n], %[n], %[m1]\n\t"
+        "v_addc_co_u32 %[n], %[dump], %[n], %[n], %[m0]"
+        : [n] "=&v"(n), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [dump] "=&s"(dump)
+        : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3));
+    return n;
+}
+
 __device__ __forceinline__ int compact_active_cells(const float *tile, unsigned short *acell, unsigned char *acase, int lane, unsigned rowmask)
 {
     const float *p0 = tile + (lane & 7) + 10 * (lane >> 3);
@@ -289,16 +338,16 @@ __device__ __forceinline__ int compact_active_cells(const float *tile, unsigned 
     unsigned nib[9];   // corners 0, 1, 2, 3 of CollectTriNum.compute:27-31 at sample layer z
 #pragma unroll
     for (int z = 0; z < 9; ++z)
-        nib[z] = (unsigned)(sm[z][0] > 0.f) | ((unsigned)(sm[z][1] > 0.f) << 1) | ((unsigned)(sm[z][2] > 0.f) << 2) | ((unsigned)(sm[z][3] > 0.f) << 3);
-    const bool y_live = ((rowmask >> (lane >> 3)) & 1u) != 0u;
+        nib[z] = sign_nibble(sm[z][0], sm[z][1], sm[z][2], sm[z][3]);
+    const u64 y_live = __builtin_amdgcn_ballot_w64(((rowmask >> (lane >> 3)) & 1u) != 0u);   // lanes of a live y layer
     int n_act = 0;
 #pragma unroll
     for (int z = 0; z < 8; ++z) {
         if (!((rowmask >> (8 + z)) & 1u)) continue;   // wave-uniform
         const unsigned cs = nib[z] | (nib[z + 1] << 4);
-        const bool on = y_live && cs != 0u && cs != 255u;
-        const u64 m = __builtin_amdgcn_ballot_w64(on);
-        if (on) {
+        // triangles <=> the case is neither 0x00 nor 0xFF <=> (cs - 1) mod 256 < 254: one compare
+        const u64 m = __builtin_amdgcn_ballot_w64(((cs - 1u) & 0xFFu) < 254u) & y_live;
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) {
             const int i = n_act + (int)lanes_below(m);
             acell[i] = (unsigned short)(64 * z + lane);
             acase[i] = (unsigned char)cs;
@@ -315,17 +364,17 @@ __device__ __forceinline__ int compact_active_cells(const float *tile, unsigned 
 // `rowmask` (bits 0-7: y layers, 8-15: z layers that hold a cell with triangles; 0xFFFF = unknown):
 // only tile rows next to such layers need to be valid, cells outside them are skipped.
 template <bool FAST>
-__device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_vert, size_t tri_base, int budget,
+__device__ __forceinline__ void emit_block_from_tile(const CornerView &L, const u64 *s_vert, size_t tri_base, int budget,
                                                      int block_id, float *__restrict__ out, int lane, int ablate,
                                                      unsigned rowmask, int &vm_issued)
 {
-    const int n_act = compact_active_cells(L->tile, L->acell, L->cases, lane, rowmask);   // pass 1
+    const int n_act = compact_active_cells(L.tile, L.acell, L.cases, lane, rowmask);   // pass 1
     VTMC_WAVE_SYNC();
 
     // pass 2: triangle slots, 64 active cells per step
     int pending = 0;
     for (int c0 = 0; c0 < n_act; c0 += 64) {
-        if (pending > kSlotCap - 320) {  // wave-uniform
+        if (pending > L.slot_cap - 320) {  // wave-uniform
             const int n_out = pending < budget ? pending : budget;
             emit_flush2<FAST>(L, n_out, tri_base, block_id, out, lane, ablate, vm_issued);
             tri_base += n_out;
@@ -334,12 +383,12 @@ __device__ __forceinline__ void emit_block_from_tile(EmitLds2 *L, const u64 *s_v
         }
         const int idx = c0 + lane;
         const bool valid = idx < n_act;
-        const unsigned cell = valid ? L->acell[idx] : 0u;
-        const u64 vw = valid ? s_vert[L->cases[idx]] : 0ull;  // fifteen 4-bit edge ids + the count in the top nibble
+        const unsigned cell = valid ? L.acell[idx] : 0u;
+        const u64 vw = valid ? s_vert[L.cases[idx]] : 0ull;  // fifteen 4-bit edge ids + the count in the top nibble
         const unsigned n = (unsigned)(vw >> 60);
         unsigned step_total;
         const unsigned pre_n = wave_prefix3(n, step_total);
-        unsigned *dst = L->slot + pending + pre_n;
+        unsigned *dst = L.slot + pending + pre_n;
 #pragma unroll
         for (unsigned i = 0; i < 5; ++i)
             if (i < n) dst[i] = cell | (((unsigned)(vw >> (12 * i)) & 0xFFFu) << 9);
@@ -375,18 +424,32 @@ __device__ __forceinline__ unsigned case_edge_mask(unsigned cs)
     const unsigned rn = (n ^ ((n >> 1) | (n << 3))) & 15u, rm = (m ^ ((m >> 1) | (m << 3))) & 15u;
     return rn | (rm << 4) | ((n ^ m) << 8);
 }
-constexpr int kVertCap = 192;          // vertices a block may hold in LDS (1024^3 perlin3d: at most 172)
-constexpr int kOnceVertsBytes = kVertCap * 24;
+constexpr int kVertCap = 176;          // vertices a block may hold in LDS (1024^3 perlin3d: at most 172)
+constexpr int kOnceSlotCap = 352;      // triangles a block may hold in LDS (1024^3 perlin3d: at most 295)
 
+// LDS of one wave of the vertex-once kernel.  Life times: tile (fetch .. V) | slot, vtab (N .. T) | acell, cases (pass 1 .. N) | vlist
+// (N .. V) | verts (V .. T) | stage (T).  The stage holds a WHOLE batch of 64 records (round 4 staged 33 at a time, two rounds per
+// batch: twice the fixed cost of a round) and lies over what is dead in T: the tile, the vertex list behind it and a pad.
 struct __attribute__((aligned(16))) EmitLdsOnce {
-    EmitLds2 c;   // tile | slot | acell | cases | stage: the per-corner path's view.  ONCE: `verts` starts at c.acell (the active
-                  // cells and their cases are dead when the first vertex is written) and the staging area lies over c.tile
-    unsigned char more[kOnceVertsBytes - (int)(sizeof(EmitLds2) - offsetof(EmitLds2, acell)) + kVertCap * 2 + 2192];
-    __device__ __forceinline__ float *verts() { return reinterpret_cast<float *>(c.acell); }
-    __device__ __forceinline__ unsigned short *vlist() { return reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(c.acell) + kOnceVertsBytes); }
-    __device__ __forceinline__ unsigned char *vtab() { return reinterpret_cast<unsigned char *>(c.acell) + kOnceVertsBytes + kVertCap * 2; }
+    unsigned slot[kOnceSlotCap];                 // triangle slot -> cell | edge triple << 9
+    float tile[1000];
+    unsigned short vlist[kVertCap + 8];          // vertex id -> low lattice point | axis << 12; entry kVertCap: dump of an overflowing block
+    unsigned char stage_tail[kOnceStageDwords * 4 - 4000 - (kVertCap + 8) * 2];
+    union {
+        struct {
+            unsigned short acell[512];           // active cells of the block, ascending cell id
+            unsigned char cases[512];            // cases[i]: the case of cell acell[i]
+            float corner_stage[kStageTris * kTriDwords + 4];   // the per-corner path's staging area (blocks that overflow the caps)
+        } p;
+        float verts[kVertCap * 6];               // {position, normal} per vertex
+    } u;
+    unsigned char vtab[2192];                    // lattice edge (axis * 729 + x + 9 y + 81 z) -> vertex id
+    __device__ __forceinline__ float *stage() { return tile; }
+    __device__ __forceinline__ CornerView corner_view() { return CornerView{tile, slot, kOnceSlotCap, u.p.acell, u.p.cases, u.p.corner_stage}; }
 };
-static_assert(offsetof(EmitLds2, acell) % 16 == 0 && sizeof(EmitLdsOnce) % 16 == 0 && sizeof(EmitLdsOnce) <= 12736, "three workgroups per CU");
+static_assert(offsetof(EmitLdsOnce, tile) % 16 == 0 && offsetof(EmitLdsOnce, u) % 16 == 0 && sizeof(EmitLdsOnce) % 16 == 0, "16-byte aligned areas");
+static_assert(offsetof(EmitLdsOnce, u) - offsetof(EmitLdsOnce, tile) >= kOnceStageDwords * 4, "the stage ends before the vertex records");
+static_assert(sizeof(EmitLdsOnce) <= 12784 - 64, "three workgroups per CU: 42 LDS granules of 1280 bytes less the shared tables, a quarter each");
 
 // per-workgroup constant tables of the ONCE path
 struct OnceTables {
@@ -490,16 +553,16 @@ template <bool FAST>
 __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_vert, const OnceTables *tb, size_t tri_base, int budget,
                                                 int block_id, float *__restrict__ out, int lane, int ablate, unsigned rowmask, int &vm_issued, PhaseClock &pc)
 {
-    if (budget > kSlotCap) {   // wave-uniform: more triangles than the slot buffer holds -- the per-corner path with its own flushes
-        emit_block_from_tile<FAST>(&L->c, s_vert, tri_base, budget, block_id, out, lane, ablate, rowmask, vm_issued);
+    if (budget > kOnceSlotCap) {   // wave-uniform: more triangles than the slot buffer holds -- the per-corner path with its own flushes
+        emit_block_from_tile<FAST>(L->corner_view(), s_vert, tri_base, budget, block_id, out, lane, ablate, rowmask, vm_issued);
         return;
     }
-    const float *tile = L->c.tile;
-    const int n_act = compact_active_cells(tile, L->c.acell, L->c.cases, lane, rowmask);   // pass 1
+    const float *tile = L->tile;
+    const int n_act = compact_active_cells(tile, L->u.p.acell, L->u.p.cases, lane, rowmask);   // pass 1
     VTMC_WAVE_SYNC();
     pc.mark(2);
-    unsigned short *vlist = L->vlist();
-    unsigned char *vtab = L->vtab();
+    unsigned short *vlist = L->vlist;
+    unsigned char *vtab = L->vtab;
 
     // N + pass 2, 64 active cells per step: vertex numbering and triangle slots.  One LDS round for the cell and its case, one for the
     // three tables; everything behind them runs on registers and compile-time constants.
@@ -508,8 +571,8 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
         const int idx = c0 + lane;
         const bool valid = idx < n_act;
         const int ic = valid ? idx : n_act - 1;
-        const unsigned cell = L->c.acell[ic];
-        const unsigned cs = valid ? (unsigned)L->c.cases[ic] : 0u;   // case 0: no edges, no triangles
+        const unsigned cell = L->u.p.acell[ic];
+        const unsigned cs = valid ? (unsigned)L->u.p.cases[ic] : 0u;   // case 0: no edges, no triangles
         const unsigned cx = cell & 7u, cy = (cell >> 3) & 7u, cz = cell >> 6;
         const unsigned b7 = (unsigned)(cx == 7u) | ((unsigned)(cy == 7u) << 1) | ((unsigned)(cz == 7u) << 2);
         const u64 vw = s_vert[cs];
@@ -519,12 +582,11 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
 #pragma unroll
         for (int r = 0; r < 12; ++r) {   // one ballot per cube edge a cell can own; a round nobody needs costs a compare and a branch
             const unsigned ed = once_edge_entry(kOwnedEdgeOrder[r]);   // folds to an immediate
-            const bool has = ((owned >> kOwnedEdgeOrder[r]) & 1u) != 0u;
-            const u64 m = __builtin_amdgcn_ballot_w64(has);
+            const u64 m = __builtin_amdgcn_ballot_w64((owned & (1u << kOwnedEdgeOrder[r])) != 0u);
             if (m == 0ull) continue;   // wave-uniform
-            if (has) {
+            if (__builtin_amdgcn_inverse_ballot_w64(m)) {   // the ballot IS the exec mask: no second compare
                 const int id = n_vert + (int)lanes_below(m);
-                if (id < kVertCap) vlist[id] = (unsigned short)(desc + (ed & 0xFFFFu));
+                vlist[id < kVertCap ? id : kVertCap] = (unsigned short)(desc + (ed & 0xFFFFu));   // entry kVertCap: the dump of a block that overflows (it leaves for the per-corner path below)
                 vtab[cell9 + (ed >> 16)] = (unsigned char)id;
             }
             n_vert += __builtin_popcountll(m);
@@ -533,8 +595,8 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
         const unsigned n = (unsigned)(vw >> 60);
         unsigned step_total;
         const unsigned pre_n = wave_prefix3(n, step_total);
-        if (pending + (int)step_total > kSlotCap) break;   // wave-uniform; cannot happen while the scan's count (budget <= kSlotCap) describes this tile: never outside the slot buffer
-        unsigned *dst = L->c.slot + pending + pre_n;
+        if (pending + (int)step_total > kOnceSlotCap) break;   // wave-uniform; cannot happen while the scan's count (budget <= kOnceSlotCap) describes this tile: never outside the slot buffer
+        unsigned *dst = L->slot + pending + pre_n;
 #pragma unroll
         for (unsigned i = 0; i < 5; ++i)
             if (i < n) dst[i] = cell | (((unsigned)(vw >> (12 * i)) & 0xFFFu) << 9);
@@ -542,14 +604,14 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
     }
     if (pending > budget) pending = budget;   // never outside the block's slice of the buffer
     if (n_vert > kVertCap) {   // wave-uniform: the slots are the per-corner path's own
-        if (pending > 0) emit_flush2<FAST>(&L->c, pending, tri_base, block_id, out, lane, ablate, vm_issued);
+        if (pending > 0) emit_flush2<FAST>(L->corner_view(), pending, tri_base, block_id, out, lane, ablate, vm_issued);
         return;
     }
     VTMC_WAVE_SYNC();
     pc.mark(3);
 
     // V: one lane per vertex, from the edge's low endpoint.  Branch-free up to the store: a lane past the end evaluates the last vertex again
-    float *verts = L->verts();
+    float *verts = L->u.verts;
     for (int s0 = 0; s0 < n_vert && !(ablate & 4); s0 += 64) {
         const int s = s0 + lane;
         float r6[6];
@@ -563,25 +625,25 @@ __device__ __forceinline__ void emit_block_once(EmitLdsOnce *L, const u64 *s_ver
     VTMC_WAVE_SYNC();
     pc.mark(4);
 
-    // T: one lane per triangle; the staging area lies over the tile, which nobody reads any more.  Two batches of 64 at a time: the
+    // T: one lane per triangle; the staging area (a whole batch) lies over the tile and the vertex list, which nobody reads any more.  Two batches of 64 at a time: the
     // look-up chain of the second (slot -> edge table -> vertex id -> vertex records: four LDS round trips) runs beside the first one's
-    float *stage = L->c.tile;
+    float *stage = L->stage();
     for (int s0 = 0; s0 < pending; s0 += 128) {
         const int sa = s0 + lane, sb = sa + 64;
         float ra[18], rb[18];
         const bool two = s0 + 64 < pending;   // wave-uniform
         if (two) {   // both chains in one basic block: the scheduler issues their loads side by side
-            once_gather_record(L->c.slot, vtab, verts, tb, sa, ra);
-            once_gather_record(L->c.slot, vtab, verts, tb, sb < pending ? sb : pending - 1, rb);
+            once_gather_record(L->slot, vtab, verts, tb, sa, ra);
+            once_gather_record(L->slot, vtab, verts, tb, sb < pending ? sb : pending - 1, rb);
         } else {
-            once_gather_record(L->c.slot, vtab, verts, tb, sa < pending ? sa : pending - 1, ra);
+            once_gather_record(L->slot, vtab, verts, tb, sa < pending ? sa : pending - 1, ra);
         }
         pc.mark(5);
         const int na = pending - s0 < 64 ? pending - s0 : 64;
-        stream_batch76(stage, ra, sa < pending, na, (tri_base + (size_t)s0) * kTriDwords, block_id, out, lane, ablate, vm_issued);
+        stream_batch76_full(stage, ra, sa < pending, na, (tri_base + (size_t)s0) * kTriDwords, block_id, out, lane, ablate, vm_issued);
         if (two) {
             const int nb = pending - s0 - 64 < 64 ? pending - s0 - 64 : 64;
-            stream_batch76(stage, rb, sb < pending, nb, (tri_base + (size_t)s0 + 64) * kTriDwords, block_id, out, lane, ablate, vm_issued);
+            stream_batch76_full(stage, rb, sb < pending, nb, (tri_base + (size_t)s0 + 64) * kTriDwords, block_id, out, lane, ablate, vm_issued);
         }
         pc.mark(6);
     }

@@ -28,23 +28,17 @@ __device__ unsigned long long *g_vtmc_emit_phases = nullptr;   // [8] shader cyc
 // Every statement is UNCONDITIONAL for the compiler -- a wave-uniform skip is a branch inside the string, a lane that needs
 // nothing loads a harmless address -- so a destination register has one definition chain and no merge (phi) a copy could be
 // inserted for while the data is still in flight.
-// one tile-row load: skipped as a whole when bit `BIT` of the wave-uniform `live` is clear
-template <int BIT, bool FIRST>
-__device__ __forceinline__ void gload_async(float &dst, unsigned voff, const char *sbase, unsigned live)
+// the two row-group loads of one tile slab (rows 0-4 / 5-9): skipped as a whole when bit `BIT` of the wave-uniform `live` is clear -- ONE
+// test and ONE branch per slab (the kernel is bound by issued instructions: round 4 tested every load on its own)
+template <int BIT>
+__device__ __forceinline__ void gload_slab_async(float &dst0, float &dst1, unsigned voff0, unsigned voff1, const char *sbase, unsigned live)
 {
-    // FIRST: the base may come straight out of a v_readlane (an SGPR reloaded from its spill lane): a VALU-written SGPR needs five
-    // wait states before a VMEM instruction reads it, and hipcc pads nothing inside the string.  The later bases of a tile are
-    // scalar adds on the first (tools/isa_audit.py checks that no VALU write of a base sits within five instructions of its load).
-    if (FIRST)
-        asm volatile("s_bitcmp0_b32 %3, %4\n\ts_cbranch_scc1 .Lskip_%=\n\ts_nop 4\n\tglobal_load_dword %0, %1, %2\n.Lskip_%=:"
-                     : "+v"(dst)
-                     : "v"(voff), "s"(sbase), "s"(live), "n"(BIT)
-                     : "scc", "memory");
-    else
-        asm volatile("s_bitcmp0_b32 %3, %4\n\ts_cbranch_scc1 .Lskip_%=\n\tglobal_load_dword %0, %1, %2\n.Lskip_%=:"
-                     : "+v"(dst)
-                     : "v"(voff), "s"(sbase), "s"(live), "n"(BIT)
-                     : "scc", "memory");
+    // the base may come straight out of a v_readlane (an SGPR reloaded from its spill lane): a VALU-written SGPR needs five wait states
+    // before a VMEM instruction reads it, and hipcc pads nothing inside the string (tools/isa_audit.py checks the distance)
+    asm volatile("s_bitcmp0_b32 %5, %6\n\ts_cbranch_scc1 .Lskip_%=\n\ts_nop 4\n\tglobal_load_dword %0, %2, %4\n\tglobal_load_dword %1, %3, %4\n.Lskip_%=:"
+                 : "+v"(dst0), "+v"(dst1)
+                 : "v"(voff0), "v"(voff1), "s"(sbase), "s"(live), "n"(BIT)
+                 : "scc", "memory");
 }
 // lane 0 takes the next ticket of `counter` (nothing happens when counter is null: static distribution)
 __device__ __forceinline__ void ticket_async(unsigned &dst, unsigned *counter)
@@ -114,12 +108,12 @@ __device__ __forceinline__ void wait_vm_at_most(int n, float (&t)[20], unsigned 
 //   waited for (round 2's synchronous loop: profiles/r05/experiments/onepass_and_sync_loop.patch).
 //   ONCE (soup only): every welded vertex of a block is evaluated one time into LDS and the records are expanded from there
 //   (emit_block_once, emit_device.h); 53 KB of LDS per workgroup: three workgroups per CU.
-//   WAVES: waves per workgroup.  The indexed output's per-wave LDS is small enough that the shared tables decide how many waves fit a CU:
-//   three-wave workgroups, six per CU = 18 waves (four-wave workgroups: 16); the kernel is latency-bound there (0.92 / 0.68 / 0.59 ms at
+//   (Round 3's three-wave workgroups of the indexed output -- six per CU = 18 waves, measured no faster than 16 -- left the library in
+//   round 5: profiles/r05/experiments/README.md.)  The indexed kernel by occupancy: 0.92 / 0.68 / 0.59 ms at
 //   8 / 12 / 16 waves).  Workgroups of more than 256 threads get fewer slots than their LDS would allow (measured, tools/_ab/occ2.hip:
 //   52 KB x 384 threads: two per CU where the occupancy query says three).
-template <bool FAST, bool INDEXED, bool ONCE = false, int WAVES = kWavesPerWg>
-__global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void emit_kernel(BlockSpace sp, DeviceTables tb,
+template <bool FAST, bool INDEXED, bool ONCE = false>
+__global__ __launch_bounds__(64 * kWavesPerWg, ONCE ? 3 : 4) void emit_kernel(BlockSpace sp, DeviceTables tb,
                                                     const uint32_t *__restrict__ offsets,
                                                     const BlockDesc *__restrict__ active,
                                                     const uint32_t *__restrict__ totals, uint32_t capacity,
@@ -129,6 +123,7 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
                                                     int use_row_masks, uint32_t *__restrict__ volume_counts, int n_volumes)
 {
     static_assert(!(ONCE && INDEXED), "ONCE is a form of the soup");
+    constexpr int WAVES = kWavesPerWg;
     const int ablate = VTMC_ABLATE(ablate_arg);   // product build: 0, every diagnostic branch below folds away
     using Lds = typename std::conditional<INDEXED, EmitLdsIdx, typename std::conditional<ONCE, EmitLdsOnce, EmitLds2>::type>::type;
     __shared__ Lds s_lds[WAVES];
@@ -137,12 +132,12 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
     __shared__ typename std::conditional<INDEXED, IdxTables, typename std::conditional<ONCE, OnceTables, NoTables>::type>::type s_once[1];
     // (cube edge, which coordinates are 7) -> owner cell offset | owner-side edge id: a table for four-wave workgroups; three-wave ones compute
     // it (blocks of more than 255 vertices only) -- their 26 832 bytes of LDS are 21 allocation granules of 1 280 bytes, six workgroups per CU
-    __shared__ unsigned short s_own_tab[INDEXED && WAVES != 3 ? 96 : 1];
-    const unsigned short *s_own = INDEXED && WAVES != 3 ? s_own_tab : nullptr;
+    __shared__ unsigned short s_own_tab[INDEXED ? 96 : 1];
+    const unsigned short *s_own = INDEXED ? s_own_tab : nullptr;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < 256; i += 64 * WAVES) s_vert[i] = tb.vert_packed[i];
-    if (INDEXED && WAVES != 3 && threadIdx.x < 96) s_own_tab[threadIdx.x] = owner_entry(threadIdx.x >> 3, threadIdx.x & 7u);
+    if (INDEXED && threadIdx.x < 96) s_own_tab[threadIdx.x] = owner_entry(threadIdx.x >> 3, threadIdx.x & 7u);
     if constexpr (INDEXED) idx_tables_init(&s_once[0], threadIdx.x);
     else if constexpr (ONCE) once_tables_init(&s_once[0], threadIdx.x);
 #ifdef VTMC_DEBUG_POISON_LDS  // diagnostic build: NaN-fill LDS so any read of a never-written word shows up in the output
@@ -167,8 +162,7 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
 
     Lds *L = &s_lds[wave];
     auto tile_of = [](Lds *l) -> float * {
-        if constexpr (ONCE) return l->c.tile;
-        else if constexpr (INDEXED) return l->t.tile;
+        if constexpr (INDEXED) return l->t.tile;
         else return l->tile;
     };
 
@@ -232,9 +226,8 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
             const unsigned o0 = need0 ? off0 : idle, o1 = need1 ? off1 : idle;
             const unsigned live = sp.zfast ? 0x3FFu : nz;   // x-fastest: a z slab nobody needs is skipped (wave-uniform)
             const char *p = src;
-#define VTMC_ROW(C)                                  \
-    gload_async<C, true>(dst[2 * C], o0, p, live);         \
-    gload_async<C, false>(dst[2 * C + 1], o1, p, live);     \
+#define VTMC_ROW(C)                                              \
+    gload_slab_async<C>(dst[2 * C], dst[2 * C + 1], o0, o1, p, live);  \
     p += slab_bytes;
             VTMC_ROW(0) VTMC_ROW(1) VTMC_ROW(2) VTMC_ROW(3) VTMC_ROW(4) VTMC_ROW(5) VTMC_ROW(6) VTMC_ROW(7) VTMC_ROW(8) VTMC_ROW(9)
 #undef VTMC_ROW
@@ -305,7 +298,7 @@ __global__ __launch_bounds__(64 * WAVES, ONCE ? 3 : (WAVES == 3 ? 5 : 4)) void e
             else if constexpr (ONCE)
                 emit_block_once<FAST>(L, s_vert, &s_once[0], (size_t)cur.tri_base, budget, cur.b, out, lane, ablate, cur.mask, vm_issued, pc);
             else
-                emit_block_from_tile<FAST>(L, s_vert, (size_t)cur.tri_base, budget, cur.b, out, lane, ablate, cur.mask, vm_issued);
+                emit_block_from_tile<FAST>(corner_view(L), s_vert, (size_t)cur.tri_base, budget, cur.b, out, lane, ablate, cur.mask, vm_issued);
             cur = nxt;
             nxt = far;
             pc.mark(7);
@@ -348,20 +341,16 @@ hipError_t launch_emit_indexed(const BlockSpace &sp, const DeviceTables &tb, con
                                uint32_t vert_capacity, void *vertices, void *indices, int n_cus, const Tuning &tune, unsigned *queue,
                                uint32_t *volume_counts, int n_volumes, hipStream_t stream)
 {
-    const bool three = tune.emit_idx_waves == 3;   // three-wave workgroups: 26 832 B of LDS (21 granules of 1 280 B), six per CU = 18 waves (<= 96 VGPRs); four-wave ones: 35.2 KB, four per CU = 16
-    int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : (three ? 6 : 4);
+    int per_cu = tune.emit_wgs_per_cu > 0 ? tune.emit_wgs_per_cu : 4;   // 35.2 KB of LDS per workgroup, <= 128 VGPRs: four per CU = 16 waves
     int wgs = n_cus * per_cu;
     wgs = (wgs + 7) & ~7;
     if (wgs > 8 + tune.emit_spare_wgs) wgs -= tune.emit_spare_wgs & ~7;
-    dim3 g(wgs), blk(three ? 192 : 256);
+    dim3 g(wgs), blk(256);
     unsigned *q = tune.emit_dynamic ? queue : nullptr;
     launch_begin();
-#define VTMC_LAUNCH_IDX(F, W) hipLaunchKernelGGL((emit_kernel<F, true, false, W>), g, blk, 0, stream, sp, tb, offsets, active, totals, tri_capacity, (float *)vertices, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, tune.emit_row_masks, volume_counts, n_volumes)
-    if (three) {
-        if (tune.emit_fast_math) VTMC_LAUNCH_IDX(true, 3);
-        else VTMC_LAUNCH_IDX(false, 3);
-    } else if (tune.emit_fast_math) VTMC_LAUNCH_IDX(true, 4);
-    else VTMC_LAUNCH_IDX(false, 4);
+#define VTMC_LAUNCH_IDX(F) hipLaunchKernelGGL((emit_kernel<F, true, false>), g, blk, 0, stream, sp, tb, offsets, active, totals, tri_capacity, (float *)vertices, tune.emit_ablate, q, tune.emit_sub_log2, voffsets, vtotals, vert_capacity, (int *)indices, tune.emit_row_masks, volume_counts, n_volumes)
+    if (tune.emit_fast_math) VTMC_LAUNCH_IDX(true);
+    else VTMC_LAUNCH_IDX(false);
 #undef VTMC_LAUNCH_IDX
     return launch_end();
 }

@@ -30,6 +30,7 @@ namespace {
 thread_local std::string g_create_error;
 // pinned tile staging a context keeps between dirty-list calls; anything larger is given back by the next small call
 constexpr size_t kStageKeepBytes = (size_t)32 << 20;
+constexpr int kStageTrimAfter = 8;   // an over-sized staging buffer goes after this many consecutive small calls: a host that alternates a big brush with small edits keeps it
 }  // namespace
 
 namespace vtmc {
@@ -459,10 +460,15 @@ int32_t vtmc_extract_grid(vtmc_ctx *ctx, const float *grid, int32_t nx, int32_t 
             std::vector<float> pageable;
             float *tiles = nullptr;
             if (tile_bytes <= ((size_t)256 << 20)) {
-                // kept between calls up to kStageKeepBytes; a larger one (a one-off big edit) is trimmed back by the next small call
-                if (tile_bytes > ctx->h_stage_bytes || (ctx->h_stage_bytes > kStageKeepBytes && tile_bytes <= kStageKeepBytes / 4)) {
+                // kept between calls up to kStageKeepBytes; a larger one (a one-off big edit) is trimmed back to kStageKeepBytes once
+                // kStageTrimAfter calls in a row were small (freeing and re-pinning tens of MB costs milliseconds and a device sync each way)
+                const bool small = ctx->h_stage_bytes > kStageKeepBytes && tile_bytes <= kStageKeepBytes / 4;
+                ctx->h_stage_small_calls = small ? ctx->h_stage_small_calls + 1 : 0;
+                const bool trim = small && ctx->h_stage_small_calls >= kStageTrimAfter;
+                if (tile_bytes > ctx->h_stage_bytes || trim) {
                     release_pinned((void **)&ctx->h_stage, &ctx->h_stage_bytes);
-                    const size_t want = std::max(tile_bytes + tile_bytes / 4, (size_t)1 << 20);
+                    ctx->h_stage_small_calls = 0;
+                    const size_t want = trim ? kStageKeepBytes : std::max(tile_bytes + tile_bytes / 4, (size_t)1 << 20);
                     const hipError_t e = hipHostMalloc((void **)&ctx->h_stage, want, hipHostMallocDefault);
                     if (e == hipSuccess) ctx->h_stage_bytes = want;
                     else ctx->h_stage = nullptr, quiet(e);   // optional: the pageable route below takes over
@@ -506,7 +512,10 @@ int32_t vtmc_extract_grid(vtmc_ctx *ctx, const float *grid, int32_t nx, int32_t 
     }
     sp.base = (const float *)ctx->input.p;
     int64_t T = 0;
-    if (int rc = extract_core(ctx, sp, block_list ? 0 : 1, 0, ctx->stream, &T)) return rc;
+    if (int rc = extract_core(ctx, sp, block_list ? 0 : 1, 0, ctx->stream, &T)) {
+        quiet(hipStreamSynchronize(ctx->stream));   // the uploads above borrow the caller's arrays: nothing of them is in flight when an error returns
+        return rc;
+    }
     if (tri_count) *tri_count = (int32_t)T;
     return VTMC_OK;
 }
@@ -766,7 +775,6 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     if (k == "emit_sub_log2") return ranged(ctx->tune.emit_sub_log2, 0, 4);
     if (k == "emit_row_masks") return ranged(ctx->tune.emit_row_masks, 0, 1);
     if (k == "emit_wgs_per_cu") return ranged(ctx->tune.emit_wgs_per_cu, 0, 8);
-    if (k == "emit_idx_waves") return ranged(ctx->tune.emit_idx_waves, 3, 4);
     // residency caps work by unused dynamic LDS; ONE workgroup per CU would ask for the whole 160 KB, which the runtime answers with abort(): refused
     if ((k == "classify_wgs_per_cu" || k == "density_wgs_per_cu") && value == 1)
         return fail(ctx, VTMC_ERR_INVALID_ARG, "tuning key '%s': a cap of one workgroup per CU is not supported (0: none, or 2 and more)", key);

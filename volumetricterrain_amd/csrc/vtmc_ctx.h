@@ -49,6 +49,7 @@ struct vtmc_ctx {
     } sign_of;                      // which buffer / layout `signs` describes
     float *h_stage = nullptr;       // pinned staging of host-gathered tiles (vtmc_extract_grid with a dirty list)
     size_t h_stage_bytes = 0;
+    int h_stage_small_calls = 0;    // consecutive calls that needed far less than an over-sized staging buffer holds (the trim waits for kStageTrimAfter of them)
     int32_t *h_origins = nullptr;   // pinned staging of the sampler's chunk origins
     size_t h_origins_bytes = 0;
     hipEvent_t ev_origins = nullptr;   // behind the upload from h_origins
@@ -84,6 +85,7 @@ struct vtmc_ctx {
     hipEvent_t ev_gather = nullptr;
     hipEvent_t ev_last_gather = nullptr;   // behind the last all-gather this context queued, on the stream it went to
     bool gather_recorded = false;
+    hipStream_t last_gather_stream = nullptr;   // the stream ev_last_gather was recorded on
     vtmc_ctx *comm_owner = nullptr;              // borrowed: whose communicator this is
     std::vector<vtmc_ctx *> comm_borrowers;      // owned: the contexts that borrowed it (detached when the owner lets go)
     std::string err;

@@ -85,7 +85,7 @@ struct Tuning {
     int emit_wgs_per_cu = 0;   // 0: the kernel's own residency (4 for the soup, 3 for the indexed output)
     int emit_sub_log2 = 1;    // dynamic mode: 2^s ticket counters per XCD
     int emit_dynamic = 1;     // per-XCD ticket counters instead of a static round-robin over the active list
-    int emit_ablate = 0;      // diagnostic builds only: 1 skip stores, 2 re-read hot tiles, 4 skip vertex math (output invalid)
+    int emit_ablate = 0;      // diagnostic builds only: 1 skip stores, 4 skip vertex math, 16 non-temporal record stores, 64 all records into the buffer's first 32 MB (output invalid)
     int classify_ablate = 0;  // diagnostic builds only: 1 no halo rows (output invalid)
     int classify_wgs_per_cu = 3;   // residency cap of the streaming classify kernel (0: none = 7 workgroups per CU; 3 measured best, A/B in profiles/r02c)
     int emit_row_masks = 1;   // emit loads only the tile rows next to cells with triangles (masks from classify)
@@ -97,7 +97,6 @@ struct Tuning {
     int gather_beside = 0;    // 1: the all-gather of a queued extract runs on a second stream beside the emit kernel (opt-in: never run with a world > 1); 0: behind it, on the caller's stream
     int emit_once = 1;        // 1 (soup, fast math): every welded vertex of a block is evaluated once into LDS, records expanded from there; 0: per triangle corner
     int emit_spare_wgs = 0;   // workgroups the emit launch leaves free (one per XCD: room for the collective's kernel beside it)
-    int emit_idx_waves = 4;   // indexed output: waves per emit workgroup (4: four workgroups = 16 waves per CU; 3: six = 18 -- measured no faster: the kernel is at its memory ceiling from 15 waves on)
 };
 
 // scan scratch layout

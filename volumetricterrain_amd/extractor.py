@@ -35,8 +35,8 @@ def density_params(kind, n, seed=1337):
 
 
 class Extractor:
-    def __init__(self, device=0):
-        self._L = _lib.load()
+    def __init__(self, device=0, lib_path=None):
+        self._L = _lib.load(lib_path)   # lib_path: another build of the library beside the product's (A/B tools)
         h = ctypes.c_void_p()
         rc = self._L.vtmc_create(device, ctypes.byref(h))
         if rc != 0:
