@@ -74,11 +74,16 @@ def parse():
                          "k's result -- the device never waits for the host.  At N > 1 both contexts issue their all-gather through ONE "
                          "communicator (vtmc_comm_share), behind the emit kernel on the one stream everything runs on: for RCCL the same as a "
                          "single context.  1: every step ends with its host wait (the latency of an isolated step, also reported as step_latency_ms)")
-    ap.add_argument("--gather-stream", default="main", choices=["side", "main"],
-                    help="N > 1: the stream the all-gather and the copy of its result are queued on.  main (default, the fewest moving parts: "
-                         "one stream, one communicator, program order): behind the emit kernel on the extract's own stream; side (opt-in until a "
-                         "world > 1 has run it): a second stream, ordered behind the extract's emit launch by an event -- the main stream never "
-                         "waits for the collective, it overlaps the next step's classify kernel")
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
+                    help="grid1024, --pipeline 2: HIP streams the two contexts queue their steps on.  2 (default): a stream each -- step k + 1's "
+                         "classify kernel starts on the CUs step k's emit kernel leaves as it drains (the emit kernel is bound by issued "
+                         "instructions, the classify kernel by memory: profiles/r05/rank_overlap_probe.txt: -4 %% of a step at N = 1, -20 %% of a "
+                         "rank's step of an 8-rank run); 1: one stream for both (rounds 2-4)")
+    ap.add_argument("--gather-stream", default=None, choices=["side", "main"],
+                    help="N > 1: the stream the all-gather and the copy of its result are queued on.  side (default with --streams 2): ONE "
+                         "stream for every collective of the rank's ONE communicator, in step order -- the same order on every rank --, each "
+                         "ordered behind its extract's emit launch by an event; no compute stream ever waits for a collective.  main (default "
+                         "with --streams 1): behind the emit kernel on the extract's own stream")
     ap.add_argument("--gather-beside", action="store_true",
                     help="N > 1, opt-in: the all-gather on the context's second stream beside the emit kernel (tuning key gather_beside)")
     ap.add_argument("--no-dense", action="store_true", help="A/B: force the per-block classify kernel")
@@ -94,6 +99,10 @@ def parse():
         args.kind = args.kind or "perlin3d"
         args.steps = 100 if args.steps is None else args.steps   # ~0.2 s of timed region: long enough for a power / busy sample to see it
         args.warmup = 5 if args.warmup is None else args.warmup
+    if args.pipeline == 1:
+        args.streams = 1
+    if args.gather_stream is None:
+        args.gather_stream = "side" if args.streams == 2 else "main"
     return args
 
 
@@ -187,6 +196,68 @@ def cpu_baseline(volumes, dim, chunk, kind_label, want_threads, n_gpus_on_box):
         "mtris_per_s": round(statistics.median(rates) * sum(totals) / (len(volumes) * cells), 2),
         "single_core_mvoxels_per_s": round(statistics.median(r for r, _ in one_runs), 2),
         "single_core_repetitions": [round(r, 2) for r, _ in one_runs],
+        "cpu_model": _cpu_model(),
+        "host_cpus": os.cpu_count(),
+        "cpu_share": share,
+        "omp": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")},
+    }
+
+
+def cpu_baseline_stream(n, chunk, kind, origins, want_threads, n_gpus_on_box, n_sample=8):
+    """The CPU leg of the streaming config (BASELINE configs[4]): the oracle's per-sample sampler + its extractor, chunk by chunk, on a
+    bounded sample of the same world -- `n_sample` chunks spread evenly over this rank's list -- both stages on the stated thread count.
+    Repetitions of >= 0.5 s as cpu_baseline(); a one-thread leg on one chunk of the sample."""
+    import ctypes
+    import oracle
+    L = oracle.lib()
+    share = cpu_share()
+    cap = 16 * max(1, n_gpus_on_box)
+    threads = want_threads or min(x for x in (share["physical_cores"], share["cgroup_quota_cores"] or 1 << 30, cap, oracle.max_threads()))
+    dim = chunk + 2
+    prm = oracle.density_params(kind, n)
+    pick = [origins[i] for i in sorted({int(round(k * (len(origins) - 1) / max(n_sample - 1, 1))) for k in range(n_sample)})]
+    blocks = oracle.all_blocks(chunk, chunk, chunk)
+    offs = np.empty(len(blocks) + 1, np.int32)
+    vol = np.empty(dim ** 3, np.float32)
+    sx, sy, sz = 1, dim, dim * dim
+
+    def one_chunk(org, nthreads, buf):
+        L.vto_density_fill_threads(ctypes.byref(prm), int(org[0]), int(org[1]), int(org[2]), dim, dim, dim, sx, sy, sz, oracle._p(vol), nthreads)
+        return L.vto_extract_grid(oracle._p(vol), sx, sy, sz, oracle._p(blocks), len(blocks), oracle._p(buf) if buf is not None else None,
+                                  len(buf) if buf is not None else 0, oracle._p(offs), None, nthreads)
+
+    totals = [one_chunk(o, threads, None) for o in pick]      # count pass: sizes the output, touches every page
+    buf = np.zeros(max(max(totals), 1), oracle.TRI_DTYPE)
+    cells = chunk ** 3
+
+    def repetition(nthreads, orgs, min_s=0.5):
+        t0 = time.perf_counter()
+        done = 0
+        while True:
+            for o in orgs:
+                one_chunk(o, nthreads, buf)
+                done += 1
+            dt = time.perf_counter() - t0
+            if dt >= min_s:
+                return done * cells / dt / 1e6, dt
+
+    repetition(threads, pick, 0.0)
+    all_runs = [repetition(threads, pick) for _ in range(5)]
+    one_runs = [repetition(1, pick[len(pick) // 2:len(pick) // 2 + 1], 0.0)]   # one chunk on one thread: seconds
+    rates = [r for r, _ in all_runs]
+    return {
+        "value": round(statistics.median(rates), 2),
+        "unit": "Mvoxels/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d chunks of %d^3 cells spread over the rank's %d (%s, sampled AND extracted by the oracle: oracle/density_ref.c + "
+                  "oracle/mc_oracle.c), OpenMP pinned close/cores, 5 repetitions of >= 0.5 s, median" % (len(pick), chunk, len(origins), kind),
+        "repetitions_mvoxels_per_s": [round(r, 2) for r in rates],
+        "repetition_seconds": [round(s, 3) for _, s in all_runs],
+        "min_mvoxels_per_s": round(min(rates), 2),
+        "max_mvoxels_per_s": round(max(rates), 2),
+        "triangles_in_sample": int(sum(totals)),
+        "single_core_mvoxels_per_s": round(statistics.median(r for r, _ in one_runs), 2),
         "cpu_model": _cpu_model(),
         "host_cpus": os.cpu_count(),
         "cpu_share": share,
@@ -303,10 +374,13 @@ def run_grid(args, torch, dist):
         kv = {k: int(v) for k, v in (item.split("=") for item in os.environ["VTMC_BENCH_TUNING"].split(","))}
         for e in exs:
             e.set_tuning(**kv)
-    # one explicit (non-default) HIP stream for everything: the library's kernels, the all-gather and the
-    # copy of the gathered counts are ordered by it
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
+    # the contexts' OWN streams (vtmc_context_stream: each on a hardware queue of its own -- ordinary HIP streams may share a queue and then
+    # run strictly in turn), wrapped for torch's copies and events: one per context in flight (--streams 2: the steps of the two contexts
+    # overlap where one kernel drains and the next ramps up), or the first context's for everything (--streams 1)
+    # (never torch's CURRENT stream: what torch allocates while a stream is current belongs to that stream in its caching allocator, and
+    # these streams die with their contexts -- torch work is put on them with `with torch.cuda.stream(...)` only where it must be)
+    streams = [torch.cuda.ExternalStream(exs[i].stream_handle()) for i in range(depth if args.streams == 2 else 1)]
+    stream = streams[0]
     prm = vt.density_params(args.kind, n)
 
     # -- setup (untimed): density field generated on the device, chunk by chunk with halos -------
@@ -332,11 +406,13 @@ def run_grid(args, torch, dist):
     flags = 2 if args.no_dense else 0
     # rank r holds chunks r, r + N, ...: chunk c sits in slot c // N of rank c % N
     perm = np.array([(ch % world) * per_rank + ch // world for ch in range(n_chunks_total)], np.intp)
-    d_ptr, s_ptr = d_field.data_ptr(), stream.cuda_stream
+    d_ptr = d_field.data_ptr()
 
     class Slot:   # what one step in flight owns besides its context
-        def __init__(self, e):
+        def __init__(self, e, st):
             self.ex = e
+            self.stream = st
+            self.s_ptr = st.cuda_stream
             self.gathered = torch.zeros((world, per_rank, 2), dtype=torch.int32, device="cuda")
             self.counts_dev = torch.zeros((per_rank, 2), dtype=torch.int32, device="cuda")   # fallback collective's send buffer
             self.gathered_host = torch.zeros((world, per_rank, 2), dtype=torch.int32).pin_memory()
@@ -347,7 +423,7 @@ def run_grid(args, torch, dist):
             self.timed_gather = False
             self.timed_stages = True
 
-    slots = [Slot(e) for e in exs]
+    slots = [Slot(e, streams[i % len(streams)]) for i, e in enumerate(exs)]
     side = torch.cuda.Stream() if (exchange and native and args.gather_stream == "side" and not args.gather_beside) else None
     stage_acc = {"classify": 0.0, "scan": 0.0, "emit": 0.0, "total": 0.0}
     stage_steps = [0]   # steps whose three kernels were timed one by one
@@ -361,11 +437,11 @@ def run_grid(args, torch, dist):
         if sample_stages:
             sl.ex.set_tuning(stage_events=1 if timed_stages else 0)
         sl.timed_stages = timed_stages
-        sl.ex.extract_volumes_device_async(d_ptr, (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, s_ptr, flags)
+        sl.ex.extract_volumes_device_async(d_ptr, (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, sl.s_ptr, flags)
         if exchange:
             sl.timed_gather = timed_gather
             if timed_gather:
-                sl.ev0.record(stream)
+                sl.ev0.record(sl.stream)
             if native and side is not None:
                 # the path's one collective, behind the C ABI, on a stream of its own: the library orders it behind this extract's emit
                 # launch (an event), the copy of the gathered pairs follows it there, and the main stream goes straight on to the next
@@ -377,20 +453,25 @@ def run_grid(args, torch, dist):
                     sl.gathered_host.copy_(sl.gathered, non_blocking=True)
                 sl.copied.record(side)
                 return
-            if native:     # --gather-stream main: behind the emit kernel on the extract's own stream (or beside it with --gather-beside)
-                sl.ex.allgather_volume_counts(sl.gathered.data_ptr(), per_rank, s_ptr)
-            else:
-                sl.ex.copy_volume_counts_device(sl.counts_dev.data_ptr(), per_rank, s_ptr)
-                if backend == "nccl":
-                    dist.all_gather_into_tensor(sl.gathered.view(-1), sl.counts_dev.view(-1))
-                else:   # gloo rehearsal: through the host
-                    stream.synchronize()
-                    g = sharding.allgather_counts(sl.counts_dev.cpu())
-                    sl.gathered.copy_(g.to("cuda"))
-            if timed_gather:
-                sl.ev1.record(stream)
-            sl.gathered_host.copy_(sl.gathered, non_blocking=True)
-            sl.copied.record(stream)
+            with torch.cuda.stream(sl.stream):
+                if native:     # --gather-stream main: behind the emit kernel on the extract's own stream (or beside it with --gather-beside)
+                    sl.ex.allgather_volume_counts(sl.gathered.data_ptr(), per_rank, sl.s_ptr)
+                else:
+                    sl.ex.copy_volume_counts_device(sl.counts_dev.data_ptr(), per_rank, sl.s_ptr)
+                    if backend == "nccl":
+                        dist.all_gather_into_tensor(sl.gathered.view(-1), sl.counts_dev.view(-1))
+                    else:   # gloo rehearsal: through the host (torch allocates nothing while a context's stream is current: see above)
+                        sl.stream.synchronize()
+                        with torch.cuda.stream(torch.cuda.default_stream()):
+                            g_dev = sharding.allgather_counts(sl.counts_dev.cpu()).to("cuda")
+                            torch.cuda.default_stream().synchronize()
+                        sl.gathered.copy_(g_dev)
+                        sl.stream.synchronize()
+                        del g_dev
+                if timed_gather:
+                    sl.ev1.record(sl.stream)
+                sl.gathered_host.copy_(sl.gathered, non_blocking=True)
+                sl.copied.record(sl.stream)
 
     def complete(sl, accumulate=False):
         """The one host wait of a step: its gathered pairs are in pinned memory (or, without an exchange, its extract is done)."""
@@ -438,15 +519,38 @@ def run_grid(args, torch, dist):
         assert int(offs[-1, 1]) == int(total_tris), "gathered chunk counts do not add up to the ranks' triangle totals"
 
     ms_per_step = elapsed / args.steps * 1e3
+    # The kernels' own durations.  With a stream per context the HIP events around a kernel also see the time it waits for CUs beside the
+    # other context's kernels (a classify kernel "takes" 1.9 ms there): the roofline of a KERNEL needs it alone on the chip.  A second
+    # region of the same K steps, the same two contexts taking turns, both on the first context's stream (rounds 1-4's timed region).
+    live = {k: v / max(stage_steps[0], 1) for k, v in stage_acc.items()}
+    serial_ms_per_step = ms_per_step
+    if len(streams) > 1:
+        for sl in slots:
+            sl.stream, sl.s_ptr = streams[0], streams[0].cuda_stream
+        for k in stage_acc:
+            stage_acc[k] = 0.0
+        stage_steps[0] = 0
+        run_steps(depth, False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(args.steps, True)
+        torch.cuda.synchronize()
+        serial_ms_per_step = (time.perf_counter() - t1) / args.steps * 1e3
+        for i, sl in enumerate(slots):
+            sl.stream, sl.s_ptr = streams[i % len(streams)], streams[i % len(streams)].cuda_stream
     # the latency of an isolated step (queue, one host wait), outside the timed region: what --pipeline 1 measures
     lat = []
+    iso = {"classify": [], "scan": [], "emit": [], "total": []}   # the three kernels with nothing beside them (no second step in flight)
     for _ in range(10):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         queue(slots[0])
         complete(slots[0])
         lat.append((time.perf_counter() - t1) * 1e3)
+        for k, v in slots[0].ex.last_stage_ms().items():
+            iso[k].append(v)
     step_latency_ms = statistics.median(lat)
+    iso = {k: statistics.median(v) for k, v in iso.items()}
     cells_total = float(world_dims[0]) * world_dims[1] * world_dims[2]
     value = cells_total / (elapsed / args.steps) / 1e6
 
@@ -470,14 +574,19 @@ def run_grid(args, torch, dist):
         roofline = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes": alg[dom], "avg_ms": round(avg[dom], 4)}
-        per_kernel = {k: {"avg_ms": round(avg[k], 4), "alg_GBps": round(alg[k] / (avg[k] * 1e-3) / 1e9, 1) if avg[k] > 0 else None}
+        roofline["measured"] = ("HIP events on the kernels' stream over %d steps, two contexts taking turns on ONE stream" % args.steps) + (
+            "" if len(streams) == 1 else " -- a second region behind the timed one (%.4f ms per step there): in the timed region the contexts have a "
+            "stream each and a kernel's events also see the time it shares the chip with the other context's kernels, see kernels.*.two_queue_span_ms" % serial_ms_per_step)
+        per_kernel = {k: {"avg_ms": round(avg[k], 4), "alg_GBps": round(alg[k] / (avg[k] * 1e-3) / 1e9, 1) if avg[k] > 0 else None,
+                          "two_queue_span_ms": round(live[k], 4) if len(streams) > 1 else None, "isolated_step_ms": round(iso[k], 4)}
                       for k in ("classify", "scan", "emit")}
-        # SURVEY.md 8d whole-path figure on one rank: 4*S + 76*T + 8*C over the device time of the three stages
+        # SURVEY.md 8d whole-path figure on one rank: 4*S + 76*T + 8*C over the time a step takes (wall clock of the timed region: with
+        # two streams the kernels of neighbouring steps overlap, the sum of their durations is more than a step)
         path_bytes = 4.0 * samples + 76.0 * T + 8.0 * n_chunks
-        path = {"bytes": path_bytes, "device_ms": round(avg["total"], 4),
-                "achieved_GBps": round(path_bytes / (avg["total"] * 1e-3) / 1e9, 1),
-                "frac_of_peak": round(path_bytes / (avg["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "read_only_frac_of_peak": round(4.0 * samples / (avg["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        path = {"bytes": path_bytes, "step_ms": round(ms_per_step, 4), "kernel_ms_sum": round(avg["total"], 4),
+                "achieved_GBps": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                "frac_of_peak": round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "read_only_frac_of_peak": round(4.0 * samples / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         # the same workload in the welded (indexed) output format -- 24 B per vertex + 12 B per triangle instead of 76 B
         # per triangle: a few steps after the timed region, N = 1 only (not part of `value`)
         indexed = None
@@ -490,7 +599,7 @@ def run_grid(args, torch, dist):
                     Ti = None
                     for i in range(k_steps + depth - 1):
                         if i < k_steps:
-                            exs[i % depth].extract_volumes_device_async(d_ptr, (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, s_ptr, flags)
+                            exs[i % depth].extract_volumes_device_async(d_ptr, (c, c, c), (1, dim, dim * dim), n_chunks, dim ** 3, slots[i % depth].s_ptr, flags)
                         if i >= depth - 1:
                             e = exs[(i - depth + 1) % depth]
                             Ti = e.extract_finish()
@@ -513,9 +622,9 @@ def run_grid(args, torch, dist):
                            "vertices": int(V), "triangles": int(Ti), "output_bytes": 24.0 * V + 12.0 * Ti,
                            "output_bytes_vs_soup": round((24.0 * V + 12.0 * Ti) / (76.0 * Ti), 4),
                            "kernels_ms": {k: round(v, 4) for k, v in acc.items()},
-                           "path_roofline": {"bytes": ibytes, "achieved_GBps": round(ibytes / (acc["total"] * 1e-3) / 1e9, 1),
-                                             "frac_of_peak": round(ibytes / (acc["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                             "read_only_frac_of_peak": round(4.0 * samples / (acc["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                           "path_roofline": {"bytes": ibytes, "achieved_GBps": round(ibytes / (ms_i * 1e-3) / 1e9, 1),
+                                             "frac_of_peak": round(ibytes / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                             "read_only_frac_of_peak": round(4.0 * samples / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                            "speedup_over_soup_step": round(ms_per_step / ms_i, 3)}
             finally:
                 for e in exs:
@@ -547,7 +656,7 @@ def run_grid(args, torch, dist):
             "data": "synthetic",
             "config": {"workload": wl, "grid": n, "chunk": c, "chunks_per_gpu": n_chunks, "kind": args.kind, "seed": 1337,
                        "pipeline": "classify(per-block) -> scan -> emit" if args.no_dense else "classify(dense) -> scan -> emit",
-                       "collective": None if world == 1 else (("rccl all-gather via libvtmc (vtmc_allgather_volume_counts), %s" % ("on a second stream behind the emit launch's event" if side is not None else "on the extract's stream")) if native
+                       "collective": None if not exchange else (("rccl all-gather via libvtmc (vtmc_allgather_volume_counts), %s" % ("on a second stream behind the emit launch's event" if side is not None else "on the extract's stream")) if native
                                                               else "torch.distributed all_gather (%s)" % backend)},
             "mtris_per_s": round(total_tris / (elapsed / args.steps) / 1e6, 1),
             "triangles_rank0": int(T),
@@ -558,8 +667,9 @@ def run_grid(args, torch, dist):
             "path_roofline": path,
             "allgather_ms": None if not gather_ms else {"avg": round(statistics.mean(gather_ms), 4), "max": round(max(gather_ms), 4),
                                                      "note": "rank 0, HIP events from the end of the emit kernel to the end of the collective (sampled on every eighth step).  With --gather-stream main (default) the collective sits on the extract's stream, between this step's emit kernel and the next step's classify kernel; with --gather-stream side it runs on a second stream beside the latter"},
-            "host_ms_per_step_beyond_kernels": round(ms_per_step - avg["total"], 4),
             "pipeline_depth": depth,
+            "streams": len(streams),
+            "one_stream_ms_per_step": round(serial_ms_per_step, 4),
             "step_latency_ms": round(step_latency_ms, 4),
             "indexed_output": indexed,
             "cpu_baseline": cpu,
@@ -567,10 +677,24 @@ def run_grid(args, torch, dist):
             "sampler_kernel_ms": round(sampler_kernel_ms, 3),
         }
         emit_line(json.dumps(out))
+    # nothing of torch's may outlive the contexts' streams: drain, drop every tensor / event that was used on them, hand cached blocks back
+    dbg = (lambda m: print("bench.py[%d]: %s" % (rank, m), file=sys.stderr, flush=True)) if os.environ.get("VTMC_BENCH_DEBUG") else (lambda m: None)
+    torch.cuda.synchronize()
+    dbg("synchronised")
+    sl = None   # a loop variable above may still hold the last slot (its events were recorded on a context's stream)
+    del slots, d_field
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    dbg("torch side released")
     for e in exs:
         e.close()
+    dbg("contexts closed")
     if world > 1:
         dist.destroy_process_group()
+    dbg("process group destroyed")
+    del streams, stream
+    dbg("streams dropped")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -583,6 +707,7 @@ def run_stream(args, torch, dist):
     dim = c + 2
     with ChunkStream(n, c, args.batch, args.kind, n, rank=rank, world_size=world, device=local, sampler_wgs_per_cu=args.sampler_wgs) as st:
         n_chunks = len(st.origins)
+        origins_rank0 = [tuple(int(v) for v in o) for o in st.origins]
         cells_total = float(n) ** 3
         for _ in range(max(args.warmup, 1)):   # buffers grow to their steady size
             st.run()
@@ -669,7 +794,8 @@ def run_stream(args, torch, dist):
             "kernels_ms_per_step_serialised": {k: round(v, 3) for k, v in kern.items()},
             "serialised_step_ms": round(serial_s * 1e3, 3),
             "overlap_gain": round(serial_s / step_s, 3),
-            "cpu_baseline": None,
+            "cpu_baseline": (cpu_baseline_stream(n, c, args.kind, origins_rank0, args.cpu_threads, torch.cuda.device_count())
+                             if (world == 1 and not args.no_cpu_baseline) else None),
         }
         emit_line(json.dumps(out))
     if world > 1:

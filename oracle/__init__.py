@@ -74,6 +74,8 @@ def lib():
         L.vto_density_permutation.argtypes = [ctypes.c_uint64, vp]
         L.vto_density_fill.argtypes = [ctypes.POINTER(DensityParams), i32, i32, i32, i32, i32, i32,
                                        i64, i64, i64, vp]
+        L.vto_density_fill_threads.argtypes = [ctypes.POINTER(DensityParams), i32, i32, i32, i32, i32, i32,
+                                               i64, i64, i64, vp, i32]
         L.vto_extract_grid_indexed.argtypes = [vp, i64, i64, i64, vp, i32, vp, i64, vp, i64, vp, vp, vp]
         L.vto_extract_grid_indexed.restype = i64
         L.vto_terrain_fill.argtypes = [vp, i32, i32, i32, ctypes.c_uint64]

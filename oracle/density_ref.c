@@ -12,6 +12,9 @@
  */
 #include <math.h>
 #include <stdint.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef struct {
     uint64_t seed;
@@ -75,12 +78,27 @@ static float noise3(const uint8_t *p, float x, float y, float z)
 
 /* Fill a (dx,dy,dz)-sample volume whose sample (0,0,0) sits at global sample index (ox,oy,oz);
  * out[i*sx + j*sy + k*sz]. */
+void vto_density_fill_threads(const vto_density_params *prm, int32_t ox, int32_t oy, int32_t oz,
+                              int32_t dx, int32_t dy, int32_t dz, int64_t sx, int64_t sy, int64_t sz, float *out, int32_t n_threads);
+
 void vto_density_fill(const vto_density_params *prm, int32_t ox, int32_t oy, int32_t oz,
                       int32_t dx, int32_t dy, int32_t dz, int64_t sx, int64_t sy, int64_t sz, float *out)
 {
+    vto_density_fill_threads(prm, ox, oy, oz, dx, dy, dz, sx, sy, sz, out, 0);
+}
+
+/* n_threads: the team of the fill (0: the OpenMP default) -- bench.py's CPU leg of the streaming config states its thread count. */
+void vto_density_fill_threads(const vto_density_params *prm, int32_t ox, int32_t oy, int32_t oz,
+                              int32_t dx, int32_t dy, int32_t dz, int64_t sx, int64_t sy, int64_t sz, float *out, int32_t n_threads)
+{
     uint8_t perm[256];
     vto_density_permutation(prm->seed, perm);
-#pragma omp parallel for collapse(2) schedule(static)
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+#pragma omp parallel for collapse(2) schedule(static) num_threads(n_threads) if (n_threads > 1)
     for (int32_t k = 0; k < dz; ++k)
         for (int32_t j = 0; j < dy; ++j)
             for (int32_t i = 0; i < dx; ++i) {

@@ -32,7 +32,10 @@ def test_single_gpu_line_carries_roofline_and_reproducible_cpu_leg():
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["kernel"] in ("classify_kernel", "emit_kernel") and 0 < r["frac"] < 1
     assert "traffic_source" in r
-    assert j["pipeline_depth"] == 2 and j["step_latency_ms"] > 0      # throughput with two steps in flight, isolated-step latency beside it
+    assert j["pipeline_depth"] == 2 and j["streams"] == 2 and j["step_latency_ms"] > 0      # throughput with two steps in flight on a stream each, isolated-step latency beside it
+    assert "ONE stream" in r["measured"] and all(k["isolated_step_ms"] > 0 and k["two_queue_span_ms"] >= k["avg_ms"] * 0.8 for k in j["kernels"].values())
+    assert j["one_stream_ms_per_step"] > 0
+    assert j["path_roofline"]["step_ms"] == j["ms_per_step"]
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and len(c["repetitions_mvoxels_per_s"]) == 5
     assert all(s >= 0.5 for s in c["repetition_seconds"])
@@ -61,6 +64,8 @@ def test_stream_config_line():
     j = run([sys.executable, "bench.py", "--config", "stream2048", "--grid", "256", "--batch", "3", "--steps", "1"])
     assert j["n_gpus"] == 1 and j["config"]["chunks_per_gpu"] == 8 and j["config"]["kind"] == "fbm8"
     assert j["value"] > 0 and j["triangles_total"] > 0
+    cb = j["cpu_baseline"]     # the CPU leg of the stream: the oracle's sampler + extractor on a bounded sample of chunks, thread count stated
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and len(cb["repetitions_mvoxels_per_s"]) == 5 and "sampled AND extracted" in cb["sample"]
     assert j["roofline"]["kernel"] in ("density_column_kernel", "classify_dense_kernel", "emit_kernel")
     assert j["roofline"]["bound"] == ("valu" if j["roofline"]["kernel"] == "density_column_kernel" else "hbm")   # the sampler is bound by vector issue
     assert j["sampler_valu"]["frac"] > 0 and j["overlap_gain"] > 0
@@ -73,9 +78,13 @@ def test_exchange_path_through_a_world_of_one_communicator():
             {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j["n_gpus"] == 1 and abs(j["triangles_total"] - 2655156) < 2000
     assert j["allgather_ms"] is not None and j["allgather_ms"]["avg"] >= 0
+    assert j["streams"] == 2 and "second stream" in j["config"]["collective"]     # the default: a stream per context, every collective on a third one
+    j0 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--streams", "1"],
+             {"VTMC_BENCH_FORCE_COMM": "1"})
+    assert j0["streams"] == 1 and "extract's stream" in j0["config"]["collective"] and j0["triangles_total"] == j["triangles_total"]
     j1 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--pipeline", "1"],
              {"VTMC_BENCH_FORCE_COMM": "1"})
-    assert j1["pipeline_depth"] == 1 and j1["triangles_total"] == j["triangles_total"]
+    assert j1["pipeline_depth"] == 1 and j1["streams"] == 1 and j1["triangles_total"] == j["triangles_total"]
     # opt-in: the collective beside the emit kernel, two contexts / communicators taking turns
     j2 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--pipeline", "2",
               "--gather-beside"], {"VTMC_BENCH_FORCE_COMM": "1"})

@@ -8,8 +8,10 @@ second context borrows the first one's communicator, vtmc_comm_share) -- the thr
 --comm: every step also queues the C ABI's all-gather (a world-of-one RCCL communicator: its stream ordering, events and
 the copy of the gathered array are real, the wire is not) -- the fixed cost of the exchange, behind the emit kernel on the
 extract's stream (the library's default); --comm-beside: on the context's second stream beside the emit kernel (opt-in);
---comm-side: on a second stream of the CALLER's, which the library orders behind the extract's emit launch -- bench.py's default at N > 1:
-the main stream never waits for the collective."""
+--comm-side: on a second stream of the CALLER's, which the library orders behind the extract's emit launch;
+--two-streams (with --pipeline): the two contexts queue their steps on a stream EACH, so step k + 1's classify kernel may start while step
+k's emit kernel drains (at full size both stages want the whole chip and nothing overlaps; at rank size a quarter of a 0.14 ms kernel is
+ramp-up and drain)."""
 import os
 import sys
 import time
@@ -29,6 +31,8 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 with_comm = any(a.startswith("--comm") for a in sys.argv[1:])
 pipelined = "--pipeline" in sys.argv[1:]
 side = torch.cuda.Stream() if "--comm-side" in sys.argv[1:] else None
+two_streams = "--two-streams" in sys.argv[1:]
+stream2 = torch.cuda.Stream() if two_streams else stream
 no_stage_events = "--no-stage-events" in sys.argv[1:]   # only the step's total is timed on the device: no events between the three kernels
 ex2 = vt.Extractor(0) if pipelined else None
 if no_stage_events:
@@ -67,16 +71,18 @@ for W in [1] + [int(a) for a in args or ["2", "4", "8"]]:
 
             def queue(i):
                 e, g, gh, ev = slots[i % 2]
-                e.extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), len(org), dim ** 3, stream.cuda_stream, 0)
+                st_i = stream if i % 2 == 0 else stream2
+                e.extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), len(org), dim ** 3, st_i.cuda_stream, 0)
                 if with_comm and side is not None:
                     e.allgather_volume_counts(g.data_ptr(), len(org), side.cuda_stream)
                     with torch.cuda.stream(side):
                         gh.copy_(g, non_blocking=True)
                     ev.record(side)
                 elif with_comm:
-                    e.allgather_volume_counts(g.data_ptr(), len(org), stream.cuda_stream)
-                    gh.copy_(g, non_blocking=True)
-                    ev.record(stream)
+                    e.allgather_volume_counts(g.data_ptr(), len(org), st_i.cuda_stream)
+                    with torch.cuda.stream(st_i):
+                        gh.copy_(g, non_blocking=True)
+                    ev.record(st_i)
 
             def take(i):
                 e, g, gh, ev = slots[i % 2]

@@ -36,7 +36,7 @@ SYMBOLS = [
     "vtmc_set_output_mode", "vtmc_last_vertex_count", "vtmc_read_indexed_mesh", "vtmc_device_indexed_results",
     "vtmc_comm_unique_id", "vtmc_comm_init_rank", "vtmc_comm_destroy", "vtmc_comm_share", "vtmc_allgather_volume_counts",
     "vtmc_copy_to_host", "vtmc_chunk_write", "vtmc_chunk_read",
-    "vtmc_extract_volumes_device_async", "vtmc_extract_finish", "vtmc_last_fill_ms",
+    "vtmc_extract_volumes_device_async", "vtmc_extract_finish", "vtmc_last_fill_ms", "vtmc_context_stream",
 ]
 COMM_ID_BYTES = 128
 
@@ -117,6 +117,7 @@ def load(path=None):
     L.vtmc_extract_volumes_device_async.argtypes = [vp, P(VolumeBatch), vp, u32]
     L.vtmc_extract_finish.argtypes = [vp, P(i64)]
     L.vtmc_last_fill_ms.argtypes = [vp, P(ctypes.c_float)]
+    L.vtmc_context_stream.argtypes = [vp, P(vp)]
     L.vtmc_device_results.argtypes = [vp, P(vp), P(vp), P(vp)]
     L.vtmc_reserve_triangles.argtypes = [vp, i64]
     L.vtmc_copy_volume_counts_device.argtypes = [vp, vp, i32, vp]

@@ -352,7 +352,20 @@ int32_t vtmc_create(int32_t device, vtmc_ctx **out_ctx)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    {
+        // The context's own stream sits on a HARDWARE QUEUE OF ITS OWN: ordinary HIP streams share a handful of queues, and two contexts whose
+        // streams land on one queue run their steps strictly one behind the other -- on queues of their own, step k + 1's classify kernel
+        // starts on the CUs step k's emit kernel leaves as it drains (profiles/r05/stream_overlap.txt: -4 % of a 1024^3 step, -20 % of a
+        // rank's step of an 8-rank run).  A stream made with a CU mask always gets its queue; the mask names every CU.
+        std::vector<uint32_t> mask((size_t)(ctx->n_cus + 31) / 32, 0xFFFFFFFFu);
+        if (ctx->n_cus % 32) mask.back() = (1u << (ctx->n_cus % 32)) - 1u;
+        e = hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)mask.size(), mask.data());
+        if (e != hipSuccess) {   // a runtime without it: an ordinary stream (the contexts then may share a queue, nothing else changes)
+            quiet(e);
+            ctx->stream = nullptr;
+            if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+        }
+    }
     for (auto &ev : ctx->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     for (auto &ev : ctx->ev_fill)
@@ -749,6 +762,13 @@ int32_t vtmc_reserve_triangles(vtmc_ctx *ctx, int64_t capacity)
     const size_t bytes = sizeof(vtmc_triangle) * (size_t)std::max<int64_t>(capacity, 1);
     if (ctx->tris.p && ctx->tris.bytes > std::max<size_t>(bytes, 256)) release(ctx->tris);  // exact size: shrinking is allowed
     return ensure(ctx, ctx->tris, bytes);
+}
+
+int32_t vtmc_context_stream(vtmc_ctx *ctx, void **stream)
+{
+    if (!ctx || !stream) return VTMC_ERR_INVALID_ARG;
+    *stream = (void *)ctx->stream;
+    return VTMC_OK;
 }
 
 int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4])

@@ -226,6 +226,13 @@ class Extractor:
     def reserve_triangles(self, capacity):
         self._check(self._L.vtmc_reserve_triangles(self._h, int(capacity)))
 
+    def stream_handle(self):
+        """The context's own hipStream_t as an integer (what stream = None means): on a hardware queue of its own.  Wrap it with
+        torch.cuda.ExternalStream to queue torch work behind a step."""
+        h = ctypes.c_void_p()
+        self._check(self._L.vtmc_context_stream(self._h, ctypes.byref(h)))
+        return h.value or 0
+
     def last_stage_ms(self):
         ms = (ctypes.c_float * 4)()
         self._check(self._L.vtmc_last_stage_ms(self._h, ctypes.byref(ms)))
