@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--grid", "--n", dest="n", type=int, default=None, help="cells per axis (reduced sizes for tests)")
     ap.add_argument("--chunk", type=int, default=128, help="cells per axis of a chunk")
     ap.add_argument("--batch", type=int, default=256, help="stream2048: chunks per double-buffered batch")
+    ap.add_argument("--stream-one-queue", action="store_true", help="stream2048: one stream for both contexts (rounds 2-4) instead of each context's sampler + extract on its own-queue stream")
     ap.add_argument("--sampler-wgs", type=int, default=None, help="stream2048: residency cap of the sampler kernel (workgroups per CU; default: the stream's own)")
     ap.add_argument("--kind", default=None, choices=["perlin3d", "fbm8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -79,11 +80,12 @@ def parse():
                          "classify kernel starts on the CUs step k's emit kernel leaves as it drains (the emit kernel is bound by issued "
                          "instructions, the classify kernel by memory: profiles/r05/rank_overlap_probe.txt: -4 %% of a step at N = 1, -20 %% of a "
                          "rank's step of an 8-rank run); 1: one stream for both (rounds 2-4)")
-    ap.add_argument("--gather-stream", default=None, choices=["side", "main"],
-                    help="N > 1: the stream the all-gather and the copy of its result are queued on.  side (default with --streams 2): ONE "
-                         "stream for every collective of the rank's ONE communicator, in step order -- the same order on every rank --, each "
-                         "ordered behind its extract's emit launch by an event; no compute stream ever waits for a collective.  main (default "
-                         "with --streams 1): behind the emit kernel on the extract's own stream")
+    ap.add_argument("--gather-stream", default="main", choices=["side", "main"],
+                    help="N > 1: the stream the all-gather and the copy of its result are queued on.  main (default): behind the emit kernel on the "
+                         "extract's own stream; with --streams 2 the collectives of the rank's ONE communicator then alternate between two streams, "
+                         "and the library chains them by events (a collective waits on the device for the one before it: csrc/comm.hip) -- RCCL sees "
+                         "them one after the other, in the same order on every rank, exactly as on one stream.  side: ONE third stream for every "
+                         "collective, each ordered behind its extract's emit launch by an event")
     ap.add_argument("--gather-beside", action="store_true",
                     help="N > 1, opt-in: the all-gather on the context's second stream beside the emit kernel (tuning key gather_beside)")
     ap.add_argument("--no-dense", action="store_true", help="A/B: force the per-block classify kernel")
@@ -101,8 +103,6 @@ def parse():
         args.warmup = 5 if args.warmup is None else args.warmup
     if args.pipeline == 1:
         args.streams = 1
-    if args.gather_stream is None:
-        args.gather_stream = "side" if args.streams == 2 else "main"
     return args
 
 
@@ -374,12 +374,12 @@ def run_grid(args, torch, dist):
         kv = {k: int(v) for k, v in (item.split("=") for item in os.environ["VTMC_BENCH_TUNING"].split(","))}
         for e in exs:
             e.set_tuning(**kv)
-    # the contexts' OWN streams (vtmc_context_stream: each on a hardware queue of its own -- ordinary HIP streams may share a queue and then
-    # run strictly in turn), wrapped for torch's copies and events: one per context in flight (--streams 2: the steps of the two contexts
+    # the contexts' streams (vtmc_context_stream; --streams 2: the ones on a hardware queue of their own -- ordinary HIP streams may share a
+    # queue and then run strictly in turn), wrapped for torch's copies and events: one per context in flight (--streams 2: the steps of the two contexts
     # overlap where one kernel drains and the next ramps up), or the first context's for everything (--streams 1)
     # (never torch's CURRENT stream: what torch allocates while a stream is current belongs to that stream in its caching allocator, and
     # these streams die with their contexts -- torch work is put on them with `with torch.cuda.stream(...)` only where it must be)
-    streams = [torch.cuda.ExternalStream(exs[i].stream_handle()) for i in range(depth if args.streams == 2 else 1)]
+    streams = [torch.cuda.ExternalStream(exs[i].stream_handle(own_queue=args.streams == 2)) for i in range(depth if args.streams == 2 else 1)]
     stream = streams[0]
     prm = vt.density_params(args.kind, n)
 
@@ -524,9 +524,14 @@ def run_grid(args, torch, dist):
     # region of the same K steps, the same two contexts taking turns, both on the first context's stream (rounds 1-4's timed region).
     live = {k: v / max(stage_steps[0], 1) for k, v in stage_acc.items()}
     serial_ms_per_step = ms_per_step
+
+    def set_streams(one):
+        for i, sl in enumerate(slots):
+            st = streams[0] if one else streams[i % len(streams)]
+            sl.stream, sl.s_ptr = st, st.cuda_stream
+
     if len(streams) > 1:
-        for sl in slots:
-            sl.stream, sl.s_ptr = streams[0], streams[0].cuda_stream
+        set_streams(True)
         for k in stage_acc:
             stage_acc[k] = 0.0
         stage_steps[0] = 0
@@ -536,8 +541,7 @@ def run_grid(args, torch, dist):
         run_steps(args.steps, True)
         torch.cuda.synchronize()
         serial_ms_per_step = (time.perf_counter() - t1) / args.steps * 1e3
-        for i, sl in enumerate(slots):
-            sl.stream, sl.s_ptr = streams[i % len(streams)], streams[i % len(streams)].cuda_stream
+        set_streams(False)
     # the latency of an isolated step (queue, one host wait), outside the timed region: what --pipeline 1 measures
     lat = []
     iso = {"classify": [], "scan": [], "emit": [], "total": []}   # the three kernels with nothing beside them (no second step in flight)
@@ -609,13 +613,17 @@ def run_grid(args, torch, dist):
                     return Ti
 
                 run_indexed(2 * depth, None)
-                acc = {"classify": 0.0, "scan": 0.0, "emit": 0.0, "total": 0.0}
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 K = max(4, args.steps // 2)
-                Ti = run_indexed(K, acc)
+                Ti = run_indexed(K, None)
                 torch.cuda.synchronize()
                 ms_i = (time.perf_counter() - t0) / K * 1e3
+                acc = {"classify": 0.0, "scan": 0.0, "emit": 0.0, "total": 0.0}   # the kernels' own durations: the same steps on one stream (see above)
+                set_streams(True)
+                run_indexed(K, acc)
+                torch.cuda.synchronize()
+                set_streams(False)
                 V = ex.last_vertex_count()
                 ibytes = 4.0 * samples + 24.0 * V + 12.0 * Ti + 8.0 * n_chunks
                 indexed = {"ms_per_step": round(ms_i, 4), "mvoxels_per_s": round(cells_total / (ms_i * 1e-3) / 1e6, 1),
@@ -705,7 +713,7 @@ def run_stream(args, torch, dist):
     rank, world, local, backend = init_distributed(args, torch, dist)
     n, c = args.n, args.chunk
     dim = c + 2
-    with ChunkStream(n, c, args.batch, args.kind, n, rank=rank, world_size=world, device=local, sampler_wgs_per_cu=args.sampler_wgs) as st:
+    with ChunkStream(n, c, args.batch, args.kind, n, rank=rank, world_size=world, device=local, sampler_wgs_per_cu=args.sampler_wgs, two_queues=not args.stream_one_queue) as st:
         n_chunks = len(st.origins)
         origins_rank0 = [tuple(int(v) for v in o) for o in st.origins]
         cells_total = float(n) ** 3

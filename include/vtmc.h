@@ -141,12 +141,14 @@ int32_t vtmc_extract_volumes_device(vtmc_ctx *ctx, const vtmc_volume_batch *batc
 int32_t vtmc_extract_volumes_device_async(vtmc_ctx *ctx, const vtmc_volume_batch *batch, void *stream, uint32_t flags);
 int32_t vtmc_extract_finish(vtmc_ctx *ctx, int64_t *tri_count);
 
-/* The context's own stream (a hipStream_t; what `stream` = NULL means everywhere above).  It sits on a hardware queue of its own: a host
- * that keeps two steps in flight gives each of its two contexts its own stream -- this one -- and the steps overlap where one kernel drains
- * and the next ramps up (ordinary HIP streams may share a queue and then run strictly in turn).  A host queues its own copies / events
- * behind a step on it.  Valid until vtmc_destroy.  (The reference has one queue: every Dispatch / GetData of BatchUpdate is in program
- * order on Unity's graphics device, VoxelTerrain.cs:365-427.) */
-int32_t vtmc_context_stream(vtmc_ctx *ctx, void **stream);
+/* A stream of the context (a hipStream_t), valid until vtmc_destroy.  own_queue = 0: the context's own stream, what `stream` = NULL means
+ * everywhere above.  own_queue = 1: a second stream that sits on a HARDWARE QUEUE OF ITS OWN (made on first request): ordinary HIP streams
+ * share a handful of hardware queues, and two contexts whose streams land on one queue run their steps strictly in turn; a host that keeps
+ * two steps in flight passes each context's own-queue stream to vtmc_extract_volumes_device_async and the steps overlap where one kernel
+ * drains and the next ramps up (bench.py --streams 2).  Measured under PyTorch's HIP 7.0 runtime; see INTEGRATION.md ("Streams") for what a
+ * plain C++ host linked against ROCm 7.2 showed.  (The reference has one queue: every Dispatch / GetData of BatchUpdate is in program order
+ * on Unity's graphics device, VoxelTerrain.cs:365-427.) */
+int32_t vtmc_context_stream(vtmc_ctx *ctx, int32_t own_queue, void **stream);
 
 /* Device pointers to the results of the last extract_* (valid until the next extract_* / destroy):
  * triangles (T x 76 B), block_tri_offsets (n_blocks+1 x u32), volume_counts (n_volumes x

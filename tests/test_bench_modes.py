@@ -78,10 +78,13 @@ def test_exchange_path_through_a_world_of_one_communicator():
             {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j["n_gpus"] == 1 and abs(j["triangles_total"] - 2655156) < 2000
     assert j["allgather_ms"] is not None and j["allgather_ms"]["avg"] >= 0
-    assert j["streams"] == 2 and "second stream" in j["config"]["collective"]     # the default: a stream per context, every collective on a third one
+    assert j["streams"] == 2 and "extract's stream" in j["config"]["collective"]     # the default: a stream per context, a step's collective behind its emit kernel (the library chains the communicator's collectives)
     j0 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--streams", "1"],
              {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j0["streams"] == 1 and "extract's stream" in j0["config"]["collective"] and j0["triangles_total"] == j["triangles_total"]
+    j3 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--gather-stream", "side"],
+             {"VTMC_BENCH_FORCE_COMM": "1"})
+    assert j3["streams"] == 2 and "second stream" in j3["config"]["collective"] and j3["triangles_total"] == j["triangles_total"]
     j1 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--pipeline", "1"],
              {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j1["pipeline_depth"] == 1 and j1["streams"] == 1 and j1["triangles_total"] == j["triangles_total"]

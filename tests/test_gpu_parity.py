@@ -650,40 +650,52 @@ def test_rccl_allgather_of_counts_through_the_c_abi(ex, oracle_mod, c, n_vol, pe
         e2.allgather_volume_counts(gathered.data_ptr(), per_rank)      # the borrower is gone, the communicator is not
         host = e2.copy_u32(gathered.data_ptr(), 2 * per_rank).reshape(per_rank, 2)
         assert list(host[:n_vol, 1]) == want
-        # bench.py's default from round 5 on (--streams 2, --gather-stream side): two contexts take turns, each queues its steps on a stream
-        # of its own, EVERY collective of the one communicator goes to a third stream in step order (the library orders each behind its
-        # extract's emit launch), the copy of the gathered pairs into pinned words follows it there; two steps in flight
+        # bench.py from round 5 on (--streams 2): two contexts take turns, each queues its steps on its own-queue stream; two steps in flight.
+        # "own" (the default, --gather-stream main): a step's collective follows its emit kernel on the step's stream -- the collectives of the
+        # ONE communicator alternate between two streams and the library chains them by events; "third" (--gather-stream side): every
+        # collective on one third stream, the library orders each behind its extract's emit launch.  The copy of the gathered pairs into
+        # pinned words follows the collective on its stream.
         with vt.Extractor(0) as e4:
             e4.set_output_mode(indexed)
             e4.comm_share(e2)
-            ctxs, sts, third = [e2, e4], [torch.cuda.Stream(), torch.cuda.Stream()], torch.cuda.Stream()
+            ctxs, third = [e2, e4], torch.cuda.Stream()
+            sts = [torch.cuda.ExternalStream(e.stream_handle(own_queue=True)) for e in ctxs]   # each context's stream on a hardware queue of its own
             gs = [torch.full((1, per_rank, 2), 0x7FFFFFFF, dtype=torch.int32, device="cuda") for _ in range(2)]
             hosts = [torch.zeros((per_rank, 2), dtype=torch.int32).pin_memory() for _ in range(2)]
             done = [torch.cuda.Event(), torch.cuda.Event()]
             torch.cuda.synchronize()
+            for route in ("own", "third", "own"):
 
-            def queue(i):
-                k = i % 2
-                with torch.cuda.stream(third):
-                    gs[k].fill_(0x7FFFFFFF)     # in front of this step's collective, behind the copy of the step two before
-                ctxs[k].extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), n_vol, dim ** 3, sts[k].cuda_stream)
-                ctxs[k].allgather_volume_counts(gs[k].data_ptr(), per_rank, third.cuda_stream)
-                with torch.cuda.stream(third):
-                    hosts[k].copy_(gs[k].view(per_rank, 2), non_blocking=True)
-                done[k].record(third)
+                def queue(i):
+                    k = i % 2
+                    cs = sts[k] if route == "own" else third
+                    with torch.cuda.stream(cs):
+                        gs[k].fill_(0x7FFFFFFF)     # in front of this step's collective, behind the copy of the step two before
+                    ctxs[k].extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), n_vol, dim ** 3, sts[k].cuda_stream)
+                    ctxs[k].allgather_volume_counts(gs[k].data_ptr(), per_rank, cs.cuda_stream)
+                    with torch.cuda.stream(cs):
+                        hosts[k].copy_(gs[k].view(per_rank, 2), non_blocking=True)
+                    done[k].record(cs)
 
-            def take(i):
-                k = i % 2
-                done[k].synchronize()
-                assert ctxs[k].extract_finish() == sum(want)
-                h = hosts[k].numpy()
-                assert list(h[:n_vol, 1]) == want and list(h[:n_vol, 0]) == want_v and not h[n_vol:].any()
+                def take(i):
+                    k = i % 2
+                    done[k].synchronize()
+                    assert ctxs[k].extract_finish() == sum(want)
+                    h = hosts[k].numpy()
+                    assert list(h[:n_vol, 1]) == want and list(h[:n_vol, 0]) == want_v and not h[n_vol:].any()
 
-            for i in range(6):
-                queue(i)
-                if i >= 1:
-                    take(i - 1)
-            take(5)
+                for i in range(6):
+                    queue(i)
+                    if i >= 1:
+                        take(i - 1)
+                take(5)
+                torch.cuda.synchronize()
+            # nothing of torch's may outlive the contexts' streams: PyTorch records an event on every stream a pinned tensor was copied on WHEN IT
+            # FREES the tensor, and events / ExternalStream wrappers hold the raw handle
+            del queue, take, sts, done, hosts, gs
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
         e2.comm_destroy()
 
 

@@ -52,10 +52,33 @@ def main():
             if k.startswith("vtmc::"):
                 real = [x for x in v if x >= 10000] or v
                 rows[k] = {"calls": len(v), "calls_under_10us": len(v) - len(real), "avg_ms_real_calls": round(sum(real) / len(real) / 1e6, 4)}
+        # round 5: bench.py's timed region has the two contexts on a stream (hardware queue) each and its kernels overlap; the kernel rooflines
+        # come from its second, one-stream region.  A call of the trace belongs to that region when no kernel of another context's step was on
+        # the chip beside it: the average over THOSE calls is what must agree with bench.py's HIP events (kernels.*.avg_ms).
+        calls = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")) for r in csv.DictReader(open(tr))
+                        if "vtmc::" in r["Kernel_Name"]), key=lambda c: c[0])
+        alone = collections.defaultdict(list)
+        for i, (s0, e0, k) in enumerate(calls):
+            if e0 - s0 < 10000:
+                continue
+            beside = any(calls[j][0] < e0 - 2000 and calls[j][1] > s0 + 2000 and calls[j][1] - calls[j][0] >= 10000 for j in range(max(0, i - 6), min(len(calls), i + 7)) if j != i)
+            if not beside:
+                alone[k].append(e0 - s0)
+        for k, v in alone.items():
+            if k in rows:
+                rows[k]["calls_alone_on_the_chip"] = len(v)
+                rows[k]["avg_ms_calls_alone"] = round(sum(v) / len(v) / 1e6, 4)
         json.dump({"rocprofv3_kernel_trace": rows, "bench_hip_events_same_run": bench_line.get("kernels"),
-                   "note": "same process: bench.py under rocprofv3 --kernel-trace --stats; the two averages of a kernel must agree"},
+                   "note": "same process: bench.py under rocprofv3 --kernel-trace --stats.  avg_ms_calls_alone (the calls of the one-stream region, where no other "
+                           "kernel of the library shares the chip) must agree with bench.py's kernels.*.avg_ms; avg_ms_real_calls mixes them with the spans of the "
+                           "two-queue region"},
                   open(os.path.join(dst, "kernel_avg_vs_bench_events.json"), "w"), indent=1)
-    for name in ("bench_n1.json", "bench_stream2048.json", "bench_2rank_one_device_gloo.json", "rank_step.txt", "rank_step_comm.txt"):
+    s1 = first(os.path.join(src, "stats_s1", "*", "*_kernel_stats.csv"))
+    if s1:
+        shutil.copy(s1, os.path.join(dst, "kernel_stats_one_stream.csv"))
+        shutil.copy(os.path.join(src, "stats_s1", "bench.json"), os.path.join(dst, "bench_under_rocprof_one_stream.json"))
+    for name in ("bench_n1.json", "bench_stream2048.json", "bench_2rank_one_device_gloo.json", "bench_world_of_one_comm.json", "rank_step.txt", "rank_step_comm.txt",
+                 "rank_overlap_probe.txt", "rank_overlap_probe_w1.txt", "ab_three_libs.txt", "sq_counters_soup.txt"):
         f = os.path.join(src, name)
         if os.path.exists(f) and os.path.getsize(f):
             if name.endswith(".json"):   # torchrun's ranks also print connection chatter on stdout: keep the JSON line

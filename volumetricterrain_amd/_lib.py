@@ -117,7 +117,8 @@ def load(path=None):
     L.vtmc_extract_volumes_device_async.argtypes = [vp, P(VolumeBatch), vp, u32]
     L.vtmc_extract_finish.argtypes = [vp, P(i64)]
     L.vtmc_last_fill_ms.argtypes = [vp, P(ctypes.c_float)]
-    L.vtmc_context_stream.argtypes = [vp, P(vp)]
+    if not explicit or hasattr(L, "vtmc_context_stream"):   # an older build loaded beside the product's (A/B tools) may lack the newest entry points
+        L.vtmc_context_stream.argtypes = [vp, i32, P(vp)]
     L.vtmc_device_results.argtypes = [vp, P(vp), P(vp), P(vp)]
     L.vtmc_reserve_triangles.argtypes = [vp, i64]
     L.vtmc_copy_volume_counts_device.argtypes = [vp, vp, i32, vp]
@@ -144,6 +145,8 @@ def load(path=None):
     L.vtmc_chunk_write.argtypes = [vp, ctypes.c_char_p, i32, P(i32 * 3), i32]
     L.vtmc_chunk_read.argtypes = [vp, ctypes.c_char_p, P(ChunkView)]
     for name in SYMBOLS:
+        if explicit and not hasattr(L, name):
+            continue
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int:
             fn.restype = i32

@@ -102,6 +102,8 @@ void drain_collectives(vtmc_ctx *ctx)
 {
     if (ctx->gather_recorded && ctx->ev_last_gather) quiet(hipEventSynchronize(ctx->ev_last_gather));
     ctx->gather_recorded = false;
+    if (ctx->comm_chain_recorded && ctx->ev_comm_chain) quiet(hipEventSynchronize(ctx->ev_comm_chain));   // an owner: the end of its communicator's chain
+    ctx->comm_chain_recorded = false;
     if (ctx->comm_stream) quiet(hipStreamSynchronize(ctx->comm_stream));
     if (ctx->pending.active && ctx->pending.stream) quiet(hipStreamSynchronize(ctx->pending.stream));
     if (ctx->stream) quiet(hipStreamSynchronize(ctx->stream));
@@ -246,15 +248,22 @@ int32_t vtmc_allgather_volume_counts(vtmc_ctx *ctx, uint32_t *d_all_counts, int3
             VTMC_HIP(ctx, hipMemcpyAsync(ctx->comm_send.p, ctx->volcounts.p, own * sizeof(uint32_t), hipMemcpyDeviceToDevice, gs));
         send = ctx->comm_send.p;
     }
+    // ONE ORDER PER COMMUNICATOR, WHATEVER THE STREAMS.  The collectives of a communicator -- its owner's and every borrower's -- form a chain of
+    // events kept by the owner: a collective that goes to another stream than the one before it waits (on the device, no host wait) for the
+    // previous one's event first.  Two contexts that take turns on a stream each (bench.py --streams 2) therefore hand RCCL its collectives
+    // exactly as a single stream would -- one after the other, the same order on every rank -- and the last event of the chain stands for all
+    // of them when the communicator is destroyed.
+    vtmc_ctx *chain = ctx->comm_borrowed && ctx->comm_owner ? ctx->comm_owner : ctx;
+    if (!chain->ev_comm_chain) VTMC_HIP(ctx, hipEventCreateWithFlags(&chain->ev_comm_chain, hipEventDisableTiming));
+    if (chain->comm_chain_recorded && chain->comm_chain_stream != gs) VTMC_HIP(ctx, hipStreamWaitEvent(gs, chain->ev_comm_chain, 0));
     VTMC_NCCL(ctx, a, a.AllGather(send, d_all_counts, words, ncclUint32, (ncclComm_t)ctx->comm, gs));
+    VTMC_HIP(ctx, hipEventRecord(chain->ev_comm_chain, gs));
+    chain->comm_chain_recorded = true;
+    chain->comm_chain_stream = gs;
     // behind the collective, on whatever stream it went to: comm_release waits for this before the communicator is destroyed
-    // (one event remembers ONE stream: when this collective went to another stream than the one before it, the earlier one is waited for
-    // first -- a communicator must never be destroyed under a collective still queued on a stream the library does not own)
     if (!ctx->ev_last_gather) VTMC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_last_gather, hipEventDisableTiming));
-    if (ctx->gather_recorded && ctx->last_gather_stream != gs) VTMC_HIP(ctx, hipEventSynchronize(ctx->ev_last_gather));
     VTMC_HIP(ctx, hipEventRecord(ctx->ev_last_gather, gs));
     ctx->gather_recorded = true;
-    ctx->last_gather_stream = gs;
     if (beside) {
         VTMC_HIP(ctx, hipEventRecord(ctx->ev_gather, gs));
         VTMC_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_gather, 0));

@@ -352,20 +352,7 @@ int32_t vtmc_create(int32_t device, vtmc_ctx **out_ctx)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    {
-        // The context's own stream sits on a HARDWARE QUEUE OF ITS OWN: ordinary HIP streams share a handful of queues, and two contexts whose
-        // streams land on one queue run their steps strictly one behind the other -- on queues of their own, step k + 1's classify kernel
-        // starts on the CUs step k's emit kernel leaves as it drains (profiles/r05/stream_overlap.txt: -4 % of a 1024^3 step, -20 % of a
-        // rank's step of an 8-rank run).  A stream made with a CU mask always gets its queue; the mask names every CU.
-        std::vector<uint32_t> mask((size_t)(ctx->n_cus + 31) / 32, 0xFFFFFFFFu);
-        if (ctx->n_cus % 32) mask.back() = (1u << (ctx->n_cus % 32)) - 1u;
-        e = hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)mask.size(), mask.data());
-        if (e != hipSuccess) {   // a runtime without it: an ordinary stream (the contexts then may share a queue, nothing else changes)
-            quiet(e);
-            ctx->stream = nullptr;
-            if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-        }
-    }
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (auto &ev : ctx->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     for (auto &ev : ctx->ev_fill)
@@ -415,7 +402,12 @@ int32_t vtmc_destroy(vtmc_ctx *ctx)
         if (ev) quiet(hipEventDestroy(ev));
     if (ctx->ev_gather) quiet(hipEventDestroy(ctx->ev_gather));
     if (ctx->ev_last_gather) quiet(hipEventDestroy(ctx->ev_last_gather));
+    if (ctx->ev_comm_chain) quiet(hipEventDestroy(ctx->ev_comm_chain));
     if (ctx->comm_stream) quiet(hipStreamDestroy(ctx->comm_stream));
+    if (ctx->queue_stream) {
+        quiet(hipStreamSynchronize(ctx->queue_stream));
+        quiet(hipStreamDestroy(ctx->queue_stream));
+    }
     if (ctx->stream) quiet(hipStreamDestroy(ctx->stream));
     delete ctx;
     return VTMC_OK;
@@ -764,10 +756,30 @@ int32_t vtmc_reserve_triangles(vtmc_ctx *ctx, int64_t capacity)
     return ensure(ctx, ctx->tris, bytes);
 }
 
-int32_t vtmc_context_stream(vtmc_ctx *ctx, void **stream)
+int32_t vtmc_context_stream(vtmc_ctx *ctx, int32_t own_queue, void **stream)
 {
     if (!ctx || !stream) return VTMC_ERR_INVALID_ARG;
-    *stream = (void *)ctx->stream;
+    *stream = nullptr;
+    if (!own_queue) {
+        *stream = (void *)ctx->stream;
+        return VTMC_OK;
+    }
+    // A stream on a HARDWARE QUEUE OF ITS OWN.  Ordinary HIP streams share a handful of queues, and two contexts whose streams land on one
+    // queue run their steps strictly one behind the other; on queues of their own, step k + 1's classify kernel starts on the CUs step k's
+    // emit kernel leaves as it drains (profiles/r05/stream_overlap.txt: -4..5 % of a 1024^3 step, -20 % of a rank's step of an 8-rank run).
+    // A stream made with a CU mask always gets its queue; the mask names every CU.  Made on first request, destroyed with the context.
+    if (!ctx->queue_stream) {
+        VTMC_HIP(ctx, hipSetDevice(ctx->device));
+        std::vector<uint32_t> mask((size_t)(ctx->n_cus + 31) / 32, 0xFFFFFFFFu);
+        if (ctx->n_cus % 32) mask.back() = (1u << (ctx->n_cus % 32)) - 1u;
+        const hipError_t e = hipExtStreamCreateWithCUMask(&ctx->queue_stream, (uint32_t)mask.size(), mask.data());
+        if (e != hipSuccess) {
+            quiet(e);
+            ctx->queue_stream = nullptr;
+            return fail(ctx, VTMC_ERR_DEVICE, "hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e));
+        }
+    }
+    *stream = (void *)ctx->queue_stream;
     return VTMC_OK;
 }
 

@@ -29,7 +29,8 @@ struct VtmcPending {
 struct vtmc_ctx {
     int device = 0;
     int n_cus = 256;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;         // the context's own stream (what `stream` = NULL means in the ABI)
+    hipStream_t queue_stream = nullptr;   // vtmc_context_stream(own_queue = 1): a stream on a hardware queue of its own, made on request
     vtmc::DeviceTables tables{nullptr, nullptr};
     VtmcDevBuf d_vert, d_trinum;
     VtmcDevBuf counts, offsets, active, partials, totals, volcounts, cases, tris, input, list, perm, origins, yrows;
@@ -85,7 +86,9 @@ struct vtmc_ctx {
     hipEvent_t ev_gather = nullptr;
     hipEvent_t ev_last_gather = nullptr;   // behind the last all-gather this context queued, on the stream it went to
     bool gather_recorded = false;
-    hipStream_t last_gather_stream = nullptr;   // the stream ev_last_gather was recorded on
+    hipEvent_t ev_comm_chain = nullptr;    // owner of a communicator: behind the LAST collective anybody issued through it (the chain of comm.hip)
+    hipStream_t comm_chain_stream = nullptr;
+    bool comm_chain_recorded = false;
     vtmc_ctx *comm_owner = nullptr;              // borrowed: whose communicator this is
     std::vector<vtmc_ctx *> comm_borrowers;      // owned: the contexts that borrowed it (detached when the owner lets go)
     std::string err;

@@ -226,11 +226,13 @@ class Extractor:
     def reserve_triangles(self, capacity):
         self._check(self._L.vtmc_reserve_triangles(self._h, int(capacity)))
 
-    def stream_handle(self):
-        """The context's own hipStream_t as an integer (what stream = None means): on a hardware queue of its own.  Wrap it with
-        torch.cuda.ExternalStream to queue torch work behind a step."""
+    def stream_handle(self, own_queue=True):
+        """A hipStream_t of the context as an integer.  own_queue=True: the stream on a hardware queue of its own (two contexts, two steps in
+        flight, steps that overlap); False: the context's own stream (what stream = None means).  Wrap it with torch.cuda.ExternalStream to
+        queue torch work behind a step -- and release every torch object that touched it (events, pinned tensors copied on it: PyTorch
+        records an event on the stream when it FREES such a tensor) before the context is closed: the stream dies with it."""
         h = ctypes.c_void_p()
-        self._check(self._L.vtmc_context_stream(self._h, ctypes.byref(h)))
+        self._check(self._L.vtmc_context_stream(self._h, 1 if own_queue else 0, ctypes.byref(h)))
         return h.value or 0
 
     def last_stage_ms(self):

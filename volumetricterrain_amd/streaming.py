@@ -3,13 +3,14 @@
 extracted batch by batch.  New in the build -- the reference caps a world at 1025 samples per axis
 (VoxelTerrain.cs:44) and has no streaming of any kind.
 
-Two vtmc contexts (density buffer + result buffers each) fed through ONE HIP stream by a single host
-thread that stays a batch ahead: sample(k + 1) and extract(k) are queued
-(vtmc_density_fill_device_async, vtmc_extract_volumes_device_async) before the host takes batch
-k - 1's result (vtmc_extract_finish waits for that extract's own event only), so the device goes
-from kernel to kernel without waiting for the host.  The sampler (ALU-bound) and the extract stages
-(HBM-bound) each want the whole chip: run side by side on two streams they took 4 % LONGER than back to
-back (profiles/r02c), so they are queued back to back.  PyTorch only provides the allocations and the stream.
+Two vtmc contexts (density buffer + result buffers each) fed by a single host thread that stays a batch
+ahead: sample(k + 1) and extract(k) are queued (vtmc_density_fill_device_async,
+vtmc_extract_volumes_device_async) before the host takes batch k - 1's result (vtmc_extract_finish waits
+for that extract's own event only), so the device goes from kernel to kernel without waiting for the host.
+Each context queues its sampler and its extract on its own-queue stream (round 5: a hardware queue each;
+rounds 2-4 used one stream for both -- two ordinary streams shared a queue and ran in turn, or lost 4 % with
+the sampler's residency cut to make room): the batches' kernels overlap where one drains and the next ramps
+up, 18.9 against 19.8 ms per 2048^3 pass.  PyTorch only provides the allocations.
 """
 import numpy as np
 
@@ -19,7 +20,7 @@ from .extractor import Extractor, density_params
 
 class ChunkStream:
     def __init__(self, world_cells, chunk=128, batch_chunks=64, kind="fbm8", noise_n=None, seed=1337,
-                 rank=0, world_size=1, device=0, sampler_wgs_per_cu=None):
+                 rank=0, world_size=1, device=0, sampler_wgs_per_cu=None, two_queues=True):
         import torch
         if isinstance(world_cells, int):
             world_cells = (world_cells,) * 3
@@ -37,6 +38,12 @@ class ChunkStream:
         with torch.cuda.device(device):
             self._buf = [torch.empty(self.batch * self.dim ** 3, dtype=torch.float32, device="cuda") for _ in range(2)]
             self._stream = torch.cuda.Stream()
+        # two_queues (default): each context's sampler and extract on the context's own-queue stream (a hardware queue each,
+        # vtmc_context_stream) instead of one stream for both: S0 E0 S2 E2 ... beside S1 E1 S3 E3 ...; 18.9 against 19.8 ms per 2048^3 pass
+        # (profiles/r05/stream2048_two_queues.txt)
+        self._sptr = [e.stream_handle() for e in self._ex] if two_queues else [self._stream.cuda_stream] * 2
+        with torch.cuda.device(device):
+            self._copy_stream = torch.cuda.Stream() if two_queues else None   # the host's read-backs never queue behind the next batch's sampler
 
     def close(self):
         for e in self._ex:
@@ -58,7 +65,7 @@ class ChunkStream:
     def _fill(self, slot, k):
         d = self.dim
         self._ex[slot].density_fill_device(self.params, self._origins_of(k), (d, d, d), (1, d, d * d), d ** 3,
-                                           self._buf[slot].data_ptr(), self._stream.cuda_stream, wait=False)
+                                           self._buf[slot].data_ptr(), self._sptr[slot], wait=False)
 
     def batches(self):
         """Yields (k, origins, T, extractor): the extractor holds batch k's results (triangles, block offsets,
@@ -76,7 +83,7 @@ class ChunkStream:
         for k in range(nb + 1):
             if k < nb:
                 self._ex[k & 1].extract_volumes_device_async(self._buf[k & 1].data_ptr(), (c, c, c), (1, d, d * d),
-                                                             len(self._origins_of(k)), d ** 3, self._stream.cuda_stream)
+                                                             len(self._origins_of(k)), d ** 3, self._sptr[k & 1])
             if k >= 1:
                 ex = self._ex[(k - 1) & 1]
                 T = ex.extract_finish()                 # batch k - 1 is done; batch k's extract is already queued behind it
@@ -89,6 +96,6 @@ class ChunkStream:
         counts, total = [], 0
         for _, org, T, ex in self.batches():
             _, _, vc_ptr = ex.device_results()
-            counts.append(ex.copy_u32(vc_ptr, 2 * len(org)).reshape(-1, 2).astype(np.int64))
+            counts.append(ex.copy_u32(vc_ptr, 2 * len(org), self._copy_stream.cuda_stream if self._copy_stream is not None else None).reshape(-1, 2).astype(np.int64))
             total += T
         return total, (np.concatenate(counts) if counts else np.zeros((0, 2), np.int64))
