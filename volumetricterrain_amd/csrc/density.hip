@@ -7,6 +7,8 @@
 // permutation from a SplitMix64-driven Fisher-Yates shuffle, summed over octaves, minus a vertical
 // ramp.  VALU + small LDS tables; writes are lane-contiguous along the stride-1 axis.
 #include "vtmc_internal.h"
+#include <type_traits>
+#pragma clang diagnostic ignored "-Winline-asm"   // the sign words' v_writelane names m0 as clobbered: a reserved register, which this file's kernels never use otherwise
 
 namespace vtmc {
 
@@ -161,13 +163,17 @@ __global__ __launch_bounds__(256) void density_row_kernel(DensityLaunch dl, cons
     for (int q = 21; q < kRowDwords; ++q) row[q] = 0.f;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32: two fmas, one issue slot
+
 struct ColOct {
-    float a0, b0, a1, b1;  // faces j = 0, 1:  S_0 = a0 + b0 * t,  S_1 = a1 + b1 * (t - 1), scaled by the octave's amplitude.  Each pair is a
-                           // pure function of (column, lattice row, octave) -- a sample never depends on where its walk started
-    float c, d;            // S_1 - S_0 = c + d * t:  c = (a1 - b1) - a0, d = b1 - b0, derived whenever a face changes
-    float ra, rb;          // fractions along the two lane axes (y walk: x, z; z walk: x, y)
-    unsigned key;          // y walk: P(X) | P(X+1) << 8 | Z << 16;  z walk: 16 * P(P(X+i)+Y+j) for (i,j) = 00 (low half), 01 (high half)
-    unsigned key2;         // z walk: the same for (i,j) = 10, 11 -- byte offsets into s_g512 before the lattice row is added
+    float a1, b1;          // the high face  S_1 = a1 + b1 * (t - 1), scaled by the octave's amplitude; the low face S_0 = a0 + b0 * t and
+                           // S_1 - S_0 = c + d * t (c = (a1 - b1) - a0, d = b1 - b0, derived whenever a face changes) live in the kernel's
+                           // PAIRED arrays (octaves 2p, 2p + 1 in one 64-bit register pair: the walk's fmas are packed).  Each face is a pure
+                           // function of (column, lattice row, octave) -- a sample never depends on where its walk started
+    float ra, rb;          // fractions along the two lane axes (x, y)
+    unsigned key;          // 16 * P(P(X+i)+Y+j) for (i,j) = 00 (low half), 01 (high half)
+    unsigned key2;         // the same for (i,j) = 10, 11 -- byte offsets into s_g512 before the lattice row is added
 };
 
 // The walk is along z, lane plane (x, y), whatever the memory layout: a sample is one function of its position (round 2 also had a walk
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     __shared__ unsigned short s_p2[256];  // P(i) | P(i+1) << 8
-    __shared__ v4f s_grad[16];            // gradient of hash h as (gx, gy, gz, 0), components in {-1, 0, 1}
+    __shared__ v4f s_grad[16];            // gradient of hash h as (gx, gy, 0, gz), components in {-1, 0, 1}: a corner's x-y dot product lands beside gz (one register pair)
     __shared__ v4f s_g512[512];      // gradient of hash P(i & 255), i = key byte + lattice row <= 511 -- one lookup per corner, no wrap
     __shared__ __attribute__((aligned(16))) float s_rows[kColSeg][kRowUsed];   // this segment's rows
     __shared__ float2 s_uv[NOCT][256];    // fade weights of the two lane axes, per octave and lane: constant along the walk, read back at a face rebuild
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
             const float su = (h & 1) ? -1.f : 1.f, sv = (h & 2) ? -1.f : 1.f;
             const bool vx = h == 12 || h == 14;
             const float g[3] = {(h < 8 ? su : 0.f) + (vx ? sv : 0.f), (h >= 8 ? su : 0.f) + (h < 4 ? sv : 0.f), (h >= 4 && !vx) ? sv : 0.f};
-            s_grad[h] = v4f{g[0], g[1], g[2], 0.f};
+            s_grad[h] = v4f{g[0], g[1], 0.f, g[2]};
         }
         {
             __syncthreads();   // s_grad
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
     {
         const long long q = (long long)pw * 256 + tid;
         live = q < (long long)dl.dx * dl.dy;
-        const long long qc = live ? q : 0;
+        const long long qc = live ? q : (long long)dl.dx * dl.dy - 1;   // past the plane's end: the plane's last column again (this workgroup's own)
         i = (int)(qc % dl.dx);
         j = (int)(qc / dl.dx);
         k = w_begin;
@@ -244,6 +250,10 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
     const float lane_ramp = ((float)(oy + j) - dl.ramp_center) * dl.ramp_scale;
 
     ColOct st[NOCT];
+    constexpr int NP = (NOCT + 1) / 2;   // octave pairs; the odd octave count's missing half stays all-zero
+    v2f a0p[NP], b0p[NP], cp[NP], dp[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) a0p[q] = b0p[q] = cp[q] = dp[q] = v2f{0.f, 0.f};
     float amp[NOCT];
     {
         float am = 1.0f;
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
                 st[o].key = ((q0 & 255u) << 4) | ((q0 >> 8) << 20);
                 st[o].key2 = ((q1 & 255u) << 4) | ((q1 >> 8) << 20);
             }
-            st[o].a0 = st[o].b0 = st[o].a1 = st[o].b1 = st[o].c = st[o].d = 0.f;
+            st[o].a1 = st[o].b1 = 0.f;
             s_uv[o][tid] = make_float2(fade(st[o].ra), fade(st[o].rb));   // only this lane ever reads its entries back
             amp[o] = am;   // wave-uniform: the compiler keeps these in SGPRs
             pa *= dl.lacunarity;
@@ -285,17 +295,15 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
             g11 = *reinterpret_cast<const v4f *>(g5 + ((key2 >> 16) + w16));
         }
         const float2 uv = s_uv[o][tid];
-        const float u = uv.x, v = uv.y;
+        const v2f u2 = {uv.x, uv.x}, v2 = {uv.y, uv.y};
         const float a0 = ra, a1 = ra - 1.0f, b0 = rb, b1 = rb - 1.0f;
-        // gradient components: A is always x; B is z (y walk) or y (z walk); the walk component is the other one
-        auto gB = [](const v4f &g) { return g.y; };
-        auto gW = [](const v4f &g) { return g.z; };
-        const float c00 = __builtin_fmaf(gB(g00), b0, g00.x * a0), c10 = __builtin_fmaf(gB(g10), b0, g10.x * a1);
-        const float c01 = __builtin_fmaf(gB(g01), b1, g01.x * a0), c11 = __builtin_fmaf(gB(g11), b1, g11.x * a1);
-        const float cu0 = __builtin_fmaf(u, c10 - c00, c00), cu1 = __builtin_fmaf(u, c11 - c01, c01);
-        const float bu0 = __builtin_fmaf(u, gW(g10) - gW(g00), gW(g00)), bu1 = __builtin_fmaf(u, gW(g11) - gW(g01), gW(g01));
-        alpha = am * __builtin_fmaf(v, cu1 - cu0, cu0);
-        beta = am * __builtin_fmaf(v, bu1 - bu0, bu0);
+        // a corner = (its gradient's x-y dot product, its gradient's component along the walk): the lerps along A then B run on both at once
+        const v2f p00 = {__builtin_fmaf(g00.y, b0, g00.x * a0), g00.w}, p10 = {__builtin_fmaf(g10.y, b0, g10.x * a1), g10.w};
+        const v2f p01 = {__builtin_fmaf(g01.y, b1, g01.x * a0), g01.w}, p11 = {__builtin_fmaf(g11.y, b1, g11.x * a1), g11.w};
+        const v2f pu0 = fma2(u2, p10 - p00, p00), pu1 = fma2(u2, p11 - p01, p01);
+        const v2f pv = fma2(v2, pu1 - pu0, pu0);
+        alpha = am * pv.x;
+        beta = am * pv.y;
     };
 
     float *dst = out + vol * dl.sv + (long long)i * dl.sx + (long long)j * dl.sy + (long long)k * dl.sz;
@@ -325,56 +333,91 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
     };
     // sign volume: word ((vol * dz + k) * 4 n_plane_wgs + 4 pw + wave), bit = lane: the sign of plane point 256 pw + tid at step k
     unsigned long long *sign_dst = signs ? signs + ((long long)vol * dl.dz + w_begin) * (4ll * n_plane_wgs) + 4 * pw + (tid >> 6) : nullptr;
-    float base_sum = 0.0f;   // sum of the low faces' constants a0 over the octaves, re-added in octave order whenever one of them changes
-    for (int jj = 0; jj < w_count; ++jj) {
-        // the step's row: five broadcast reads (every lane the same address)
+    v2f base_sum = {0.f, 0.f};   // sums of the low faces' constants a0 over the even | odd octaves, re-added in octave order whenever one of them changes
+    // one step of the walk from its row in LDS: rebuilds (when `rebuild`: some octave enters a new lattice cell here -- the same for every lane)
+    // and the sample
+    auto step_value = [&](int jj, bool rebuild) __attribute__((always_inline)) {
+        // the step's row: broadcast reads (every lane the same address)
         const v4f *rp = reinterpret_cast<const v4f *>(s_rows[jj]);
-        const v4f ta = rp[0], tb = rp[1], va = rp[2], vb = rp[3], ma = rp[4];
-        const float t[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
-        const float fv[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-        const unsigned m1 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.y)), m2 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.z));
-        if (m1 | m2) {   // some octave enters a new lattice cell at this step (the same for every lane: wave-uniform)
+        const v4f ta = rp[0], tb = rp[1], va = rp[2], vb = rp[3];
+        const v2f t2[4] = {ta.xy, ta.zw, tb.xy, tb.zw}, f2[4] = {va.xy, va.zw, vb.xy, vb.zw};
+        if (rebuild) {
+            const v4f ma = rp[4];
+            const unsigned m1 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.y)), m2 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.z));
             const unsigned wc[2] = {(unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(ma.w)),
                                     (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_rows[jj][20]))};
 #pragma unroll
             for (int o = 0; o < NOCT; ++o) {
                 if ((m1 | m2) & (1u << o)) {
                     const unsigned W = (wc[o >> 2] >> (8 * (o & 3))) & 255u;
-                    if (m2 & (1u << o)) {
-                        face(st[o], o, W, amp[o], st[o].a0, st[o].b0);
-                    } else {   // the high face of the cell just left is the low face of this one, bit for bit
-                        st[o].a0 = st[o].a1;
-                        st[o].b0 = st[o].b1;
-                    }
+                    float lo_a = st[o].a1, lo_b = st[o].b1;   // the high face of the cell just left is the low face of this one, bit for bit
+                    if (m2 & (1u << o)) face(st[o], o, W, amp[o], lo_a, lo_b);
                     face(st[o], o, W + 1u, amp[o], st[o].a1, st[o].b1);
-                    st[o].c = (st[o].a1 - st[o].b1) - st[o].a0;   // S_1(t) = a1 + b1 (t - 1)
-                    st[o].d = st[o].b1 - st[o].b0;
+                    a0p[o >> 1][o & 1] = lo_a;
+                    b0p[o >> 1][o & 1] = lo_b;
+                    cp[o >> 1][o & 1] = (st[o].a1 - st[o].b1) - lo_a;   // S_1(t) = a1 + b1 (t - 1)
+                    dp[o >> 1][o & 1] = st[o].b1 - lo_b;
                 }
             }
-            base_sum = 0.0f;
+            base_sum = a0p[0];
 #pragma unroll
-            for (int o = 0; o < NOCT; ++o) base_sum += st[o].a0;
+            for (int q = 1; q < NP; ++q) base_sum += a0p[q];
         }
         // noise_o = S_0 + fade(t) (S_1 - S_0) = a0 + b0 t + fade(t) (c + d t): three fmas per octave on top of the constant part
-        float sum = base_sum;
+        // packed: octaves 2p | 2p + 1 in the halves of one v_pk_fma_f32 (the sampler is bound by the VALU's issue slots: 61 a step in round 4,
+        // 24 of them these fmas); even and odd octaves accumulate apart and meet at the end
+        v2f acc = base_sum;
 #pragma unroll
-        for (int o = 0; o < NOCT; ++o) {
-            sum = __builtin_fmaf(st[o].b0, t[o], sum);
-            sum = __builtin_fmaf(fv[o], __builtin_fmaf(st[o].d, t[o], st[o].c), sum);
+        for (int q = 0; q < NP; ++q) {
+            acc = fma2(b0p[q], t2[q], acc);
+            acc = fma2(f2[q], fma2(dp[q], t2[q], cp[q]), acc);
         }
-        const float value = sum - lane_ramp;
-        if constexpr (ZT) {
-            s_tr[jj % kTrSteps][tid] = value;
+        return (acc.x + acc.y) - lane_ramp;
+    };
+    if constexpr (ZT) {
+        for (int jj = 0; jj < w_count; ++jj) {
+            const unsigned mm = __builtin_amdgcn_readfirstlane(__float_as_uint(s_rows[jj][17]) | __float_as_uint(s_rows[jj][18]));
+            s_tr[jj % kTrSteps][tid] = step_value(jj, mm != 0u);
             if (jj % kTrSteps == kTrSteps - 1 || jj == w_count - 1) flush_transposed(jj - jj % kTrSteps, jj % kTrSteps + 1);   // workgroup-uniform
-        } else {
-            if (live && (!(VTMC_ABLATE(dl.ablate) & 1) || sum == 1e30f)) *dst = value;   // ablate 1: diagnostics, no stores
-            dst += dst_step;
         }
-        if (signs) {   // the sign volume (z walk only): one ballot per wave and step -- what the classify stage needs of this sample
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(value > 0.f);   // lanes past the plane's end own bits nobody reads
-            if ((tid & 63) == 0) *sign_dst = m;
-            sign_dst += 4 * n_plane_wgs;
-        }
+    } else {
+        // The sampler is bound by ISSUED instructions like the emit kernel (a SIMD retires one per four cycles whatever its kind), and round 4's
+        // step spent ~38 of its ~62 on things that are not its 24 fmas.  Per 64 steps now: ONE ballot says which steps rebuild anything (a bit
+        // test per step instead of two readfirstlanes + or + compare, and the mask row is read only where it is needed); no exec mask around
+        // the stores at all (a lane past the plane's end walks the plane's LAST column: the same value to the same address as that column's
+        // own lane); a step's sign ballot goes into lane (step % 64) of a register pair (two v_writelane) and the chunk's 64 words leave in
+        // ONE store instead of a compare + exec dance per step.
+        const long long sign_pitch = 4ll * n_plane_wgs;
+        const int lane = tid & 63;
+        const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
+        auto walk = [&](auto with_signs) {
+            for (int c0 = 0; c0 < w_count; c0 += 64) {
+                const int n = __builtin_amdgcn_readfirstlane(w_count - c0 < 64 ? w_count - c0 : 64);   // workgroup-uniform: keeps the step loop's bound scalar
+                const int jl = c0 + lane < w_count ? c0 + lane : w_count - 1;
+                unsigned long long reb = __builtin_amdgcn_ballot_w64(((__float_as_uint(s_rows[jl][17]) | __float_as_uint(s_rows[jl][18])) != 0u) && lane < n);
+                unsigned slo = 0u, shi = 0u;   // lane j: the sign ballot of step c0 + j
+                for (int j = 0; j < n; ++j) {
+                    const bool rebuild = ((unsigned)reb & 1u) != 0u;
+                    reb >>= 1;
+                    const float value = step_value(c0 + j, rebuild);
+                    if (!(VTMC_ABLATE(dl.ablate) & 1) || value == 1e30f) *dst = value;   // ablate 1: diagnostics, no stores
+                    dst += dst_step;
+                    if constexpr (decltype(with_signs)::value) {
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(value > 0.f);
+                        // two SGPRs in one VOP3 break gfx9's constant-bus rule: the lane select goes through m0 (which nothing else in this kernel uses)
+                        asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                                     : "+v"(slo), "+v"(shi)
+                                     : "s"((unsigned)m), "s"((unsigned)(m >> 32)), "s"(j)
+                                     : "m0");
+                    }
+                }
+                // the sign volume (z walk only): word ((vol * dz + k) * 4 n_plane_wgs + 4 pw + wave), bit = lane: lane j writes step c0 + j's
+                // word; the bits of lanes past the plane's end are 0
+                if constexpr (decltype(with_signs)::value)
+                    if (lane < n) sign_dst[(long long)(c0 + lane) * sign_pitch] = (((unsigned long long)shi << 32) | slo) & live_mask;
+            }
+        };
+        if (signs) walk(std::true_type{}); else walk(std::false_type{});
     }
 }
 
