@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void density_generic_kernel(DensityLaunch dl, 
 // ----------------------------------------------------------------------------------------------
 constexpr int kColSeg = 160;    // steps one workgroup walks before the next segment starts with a two-face rebuild (20 KB of rows in LDS)
 constexpr int kRowUsed = 24;    // dwords of a row the walk reads
-constexpr int kRowDwords = 24;  // [0..7] t, [8..15] fade(t), 16 ramp (y walk), 17 mask "next cell", 18 mask "rebuild both faces", 19/20 cell & 255 of octaves 0-3 / 4-7
+constexpr int kRowDwords = 24;  // [0..7] t, [8..15] fade(t), 16 ramp (y walk), 17 masks "next cell" | "rebuild both faces" << 8, 18 free, 19/20 cell & 255 of octaves 0-3 / 4-7
 
 // one thread per (volume, step): the row of everything that depends on the walk coordinate alone
 __global__ __launch_bounds__(256) void density_row_kernel(DensityLaunch dl, const int *__restrict__ origins, int axis, int n_steps,
@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256) void density_row_kernel(DensityLaunch dl, cons
         yp *= dl.lacunarity;
     }
     row[16] = axis == 1 ? (pw - dl.ramp_center) * dl.ramp_scale : 0.f;
-    row[17] = __uint_as_float(m1);
-    row[18] = __uint_as_float(m2);
+    row[17] = __uint_as_float(m1 | (m2 << 8));   // one word: the walk asks "does this step rebuild anything" with one test
+    row[18] = 0.f;
     row[19] = __uint_as_float(yc[0]);
     row[20] = __uint_as_float(yc[1]);
     for (int q = 21; q < kRowDwords; ++q) row[q] = 0.f;
@@ -337,13 +337,10 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
     // one step of the walk from its row in LDS: rebuilds (when `rebuild`: some octave enters a new lattice cell here -- the same for every lane)
     // and the sample
     auto step_value = [&](int jj, bool rebuild) __attribute__((always_inline)) {
-        // the step's row: broadcast reads (every lane the same address)
         const v4f *rp = reinterpret_cast<const v4f *>(s_rows[jj]);
-        const v4f ta = rp[0], tb = rp[1], va = rp[2], vb = rp[3];
-        const v2f t2[4] = {ta.xy, ta.zw, tb.xy, tb.zw}, f2[4] = {va.xy, va.zw, vb.xy, vb.zw};
         if (rebuild) {
             const v4f ma = rp[4];
-            const unsigned m1 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.y)), m2 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.z));
+            const unsigned m12 = __builtin_amdgcn_readfirstlane(__float_as_uint(ma.y)), m1 = m12 & 255u, m2 = m12 >> 8;
             const unsigned wc[2] = {(unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(ma.w)),
                                     (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_rows[jj][20]))};
 #pragma unroll
@@ -362,21 +359,25 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
             base_sum = a0p[0];
 #pragma unroll
             for (int q = 1; q < NP; ++q) base_sum += a0p[q];
+            base_sum.x -= lane_ramp;   // the ramp rides in the accumulator's start: nothing to subtract per step
         }
         // noise_o = S_0 + fade(t) (S_1 - S_0) = a0 + b0 t + fade(t) (c + d t): three fmas per octave on top of the constant part
         // packed: octaves 2p | 2p + 1 in the halves of one v_pk_fma_f32 (the sampler is bound by the VALU's issue slots: 61 a step in round 4,
         // 24 of them these fmas); even and odd octaves accumulate apart and meet at the end
+        // the step's row: broadcast reads (every lane the same address), AFTER the rebuild: sixteen registers a face does not have to work around
+        const v4f ta = rp[0], tb = rp[1], va = rp[2], vb = rp[3];
+        const v2f t2[4] = {ta.xy, ta.zw, tb.xy, tb.zw}, f2[4] = {va.xy, va.zw, vb.xy, vb.zw};
         v2f acc = base_sum;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             acc = fma2(b0p[q], t2[q], acc);
             acc = fma2(f2[q], fma2(dp[q], t2[q], cp[q]), acc);
         }
-        return (acc.x + acc.y) - lane_ramp;
+        return acc.x + acc.y;   // (two chains over pairs 0, 1 | 2, 3 were tried for the shorter dependence: 1 % slower, the extra add costs more)
     };
     if constexpr (ZT) {
         for (int jj = 0; jj < w_count; ++jj) {
-            const unsigned mm = __builtin_amdgcn_readfirstlane(__float_as_uint(s_rows[jj][17]) | __float_as_uint(s_rows[jj][18]));
+            const unsigned mm = __builtin_amdgcn_readfirstlane(__float_as_uint(s_rows[jj][17]));
             s_tr[jj % kTrSteps][tid] = step_value(jj, mm != 0u);
             if (jj % kTrSteps == kTrSteps - 1 || jj == w_count - 1) flush_transposed(jj - jj % kTrSteps, jj % kTrSteps + 1);   // workgroup-uniform
         }
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
             for (int c0 = 0; c0 < w_count; c0 += 64) {
                 const int n = __builtin_amdgcn_readfirstlane(w_count - c0 < 64 ? w_count - c0 : 64);   // workgroup-uniform: keeps the step loop's bound scalar
                 const int jl = c0 + lane < w_count ? c0 + lane : w_count - 1;
-                unsigned long long reb = __builtin_amdgcn_ballot_w64(((__float_as_uint(s_rows[jl][17]) | __float_as_uint(s_rows[jl][18])) != 0u) && lane < n);
+                unsigned long long reb = __builtin_amdgcn_ballot_w64(__float_as_uint(s_rows[jl][17]) != 0u && lane < n);
                 unsigned slo = 0u, shi = 0u;   // lane j: the sign ballot of step c0 + j
                 for (int j = 0; j < n; ++j) {
                     const bool rebuild = ((unsigned)reb & 1u) != 0u;
