@@ -49,8 +49,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
-# vector-ALU issue peak for plain (non-packed) FP32 instructions: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.  The guide's 157.3 TFLOP/s
-# FP32 vector figure is twice that and needs v_pk_fma_f32 on both halves; measured on this kernel, packed FP32 was slower.
+# vector-ALU ISSUE peak: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = one vector instruction per SIMD every four cycles, packed or not (the guide's
+# 157.3 TFLOP/s FP32 vector figure = this x 2 halves of a v_pk_fma_f32 x 2 flops).  The sampler's model below counts issue slots: round 5 packed
+# its fmas, so an octave pair's three fmas are three slots, not six.
 VALU_PEAK_LANE_OPS = 39.3e12
 
 
@@ -763,12 +764,15 @@ def run_stream(args, torch, dist):
             alg_bytes = 76.0 * total / nb           # + 4000 B per non-empty block, not counted here
         avg_ms = kern[dom] / nb
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-        # the sampler's own bound is the vector ALU.  Instructions per sample, counted in the kernel's ISA: 3 fmas per
-        # octave + 8 for the step (row unpack, store, loop) + 4 for the sign bits the classify stage reads; a face rebuild is 34, at
-        # f * lacunarity^o rebuilds per sample and octave; a step with any rebuild re-adds the octaves' constants.  Reported next
-        # to the HBM figure.
+        # the sampler's own bound is the vector ALU's issue slots.  Vector instructions per sample, counted in the kernel's ISA (DESIGN.md 4,
+        # profiles/r05/sampler_valu_bound.txt): 3 packed fmas per octave PAIR + 7 for the step (sum, sign compare, two v_writelane for the sign
+        # word, store address, LDS address, one spare); a rebuilt octave is 27 (a face 22: 4 addresses, 2 + 8 for the corner dot products, 6 packed
+        # lerps, 2 amplitude; 5 for the derived constants), at f * lacunarity^o rebuilds per sample and octave; a step with any rebuild costs 7
+        # (mask words to scalars, the constants' sum); a walk starts with two faces per octave and ~25 per octave of column set-up.  The counter
+        # (SQ_INSTS_VALU) reads 43 per sample for config 5, this model 39.
         rates = [min(1.0, st.params.frequency * (st.params.lacunarity ** o)) for o in range(octaves)]
-        lane_ops = samples * (3.0 * octaves + 12.0 + 34.0 * sum(rates) + octaves * max(rates))
+        lane_ops = samples * (1.5 * octaves + 7.0 + 27.0 * sum(rates) + 7.0 * max(rates) + (2 * 27.0 + 25.0) * octaves / st.dim)
+        sampler_flops = samples * (2.0 * 3.0 * octaves + 2.0 * 34.0 * sum(rates))   # the arithmetic itself: 3 fmas per octave and sample, ~34 flop-pairs a face
         out = {
             "metric": "streamed sampler + marching-cubes extraction throughput on a %d^3 %s world (Mvoxels/s)" % (n, args.kind),
             "value": round(cells_total / step_s / 1e6, 1),
@@ -798,7 +802,8 @@ def run_stream(args, torch, dist):
                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                           "algorithmic_bytes": alg_bytes, "avg_ms": round(avg_ms, 4), "launches_per_step": nb}),
             "sampler_valu": {"lane_ops_per_step": lane_ops, "achieved_lane_ops_per_s": round(lane_ops / (sum(fill_ms) * 1e-3), 1),
-                             "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "frac": round(lane_ops / (sum(fill_ms) * 1e-3) / VALU_PEAK_LANE_OPS, 4)},
+                             "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "frac": round(lane_ops / (sum(fill_ms) * 1e-3) / VALU_PEAK_LANE_OPS, 4),
+                             "fp32_tflops": round(sampler_flops / (sum(fill_ms) * 1e-3) / 1e12, 2), "fp32_vector_peak_tflops": 157.3},
             "kernels_ms_per_step_serialised": {k: round(v, 3) for k, v in kern.items()},
             "serialised_step_ms": round(serial_s * 1e3, 3),
             "overlap_gain": round(serial_s / step_s, 3),
