@@ -109,19 +109,23 @@ __global__ __launch_bounds__(256) void density_generic_kernel(DensityLaunch dl, 
 // every layout.  What makes the sampler cheap is what is UNIFORM or CONSTANT along the walk:
 //   * everything that depends on the walk coordinate alone (lattice cell, fraction, fade weight,
 //     which octaves enter a new cell) is the same for every lane of every wave at that step: a small
-//     kernel writes it once per (volume, step) into a 128-byte row; a workgroup stages the rows of its
-//     segment in LDS once and every step reads its row back with six broadcast ds_read_b128 (scalar
-//     loads of the rows were tried first: one scalar-cache miss per step, ~900 cycles, stalls every wave
-//     of the workgroup at once and cannot be prefetched further than one row -- lgkmcnt is the only
-//     counter and scalar loads return out of order);
+//     kernel writes it once per (volume, step) into a 96-byte row; a workgroup stages the rows of its
+//     segment in LDS once and every step reads its row back with four broadcast ds_read_b128 (+ two on a
+//     step that rebuilds).  Scalar loads of the rows were tried twice: round 2 without a prefetch (one
+//     scalar-cache miss per step, ~900 cycles, every wave of the workgroup at once), round 5 with the next
+//     row's s_load_dwordx16 a step ahead and the fmas reading SGPR pairs: 23 % slower than the LDS rows;
 //   * inside one lattice cell the eight gradient dot products are linear in the walk fraction t and
 //     the interpolation weights of the two lane axes are constant, so the two lane-interpolated faces
 //     of the cell collapse to S_j(t) = alpha_j + beta_j * t (j = low / high face) and a sample is
-//         noise = mix(fade(t), alpha_0 + beta_0 * t, alpha_1 + beta_1 * (t - 1))
-//     -- 5 VALU instructions per octave instead of 8 hashes + 8 gradients + 7 lerps;
+//         noise = mix(fade(t), alpha_0 + beta_0 * t, alpha_1 + beta_1 * (t - 1)) = a0 + b0 t + fade(t) (c + d t)
+//     -- three fmas per octave instead of 8 hashes + 8 gradients + 7 lerps, and PACKED: octaves 2p | 2p + 1
+//     in the halves of one v_pk_fma_f32.  The kernel is bound by the vector ALU's issue slots (round 4: 61
+//     vector instructions per 64 samples x 4 cycles = its duration; now 43: profiles/r05/sampler_valu_bound.txt);
 //   * the (alpha, beta) pairs are rebuilt only when the walk enters a new cell (wave-uniform: a bit of
 //     the row's mask word); stepping into the next cell re-uses the high face as the new low face, so
-//     one face = 4 LDS lookups of gradient vectors (the x-y part of the hash chain is constant along the walk).
+//     one face = 4 LDS lookups of gradient vectors (the x-y part of the hash chain is constant along the walk), and
+//     its lerps over the two lane axes run on (x-y dot product, gz) PAIRS: the dot product is written into the
+//     spare third component of the gradient it came from (table layout gx, gy, 0, gz).
 // Same noise definition as the per-sample kernel above and as oracle/density_ref.c; the lerp order
 // (lane axes first, walk axis last) and the fma contractions move results by a few 1e-7 (bar of the
 // twin test: 2e-6).
