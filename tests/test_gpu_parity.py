@@ -338,7 +338,7 @@ def test_sharded_host_entry(ex, oracle_mod):
 
 def test_density_sampler_matches_cpu_twin(ex, oracle_mod):
     """The wave64 column sampler against the per-sample CPU twin (oracle/density_ref.c): x-fastest volumes, the C# z-fastest
-    layout and a padded x-fastest volume, several volumes with non-zero origins, 1 / 3 / 8 octaves, and the per-sample kernel that
+    layout and a padded x-fastest volume, several volumes with non-zero origins, 1 / 2 / 3 / 5 / 7 / 8 octaves, and the per-sample kernel that
     serves more than 8 octaves.  The sampler is ONE function of position: whatever the memory layout, the walk is along z with the
     same operation order, so the x-fastest, the z-fastest and the padded fill of the same points agree BIT FOR BIT."""
     import torch
@@ -364,7 +364,7 @@ def test_density_sampler_matches_cpu_twin(ex, oracle_mod):
     # three ragged volumes at non-zero origins, padded rows (stride_y > dim_x)
     dims, pad = (40, 300, 24), 48
     orgs = [(7, 100, 3), (512, 0, 77), (1000, 1700, 1999)]
-    for octaves in (1, 3, 8, 11):
+    for octaves in (1, 2, 3, 5, 7, 8, 11):   # odd counts: the packed walk's last octave pair has an empty half
         prm = vt.density_params("fbm8", 2048)
         prm.octaves = octaves
         oprm = oracle_mod.density_params("fbm8", 2048)
