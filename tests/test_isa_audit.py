@@ -17,6 +17,17 @@ def test_no_compiler_instruction_touches_a_register_with_an_asm_load_in_flight()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_audit.py")], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-4000:] + p.stderr[-2000:]
     assert "asm loads, 0 findings" in p.stdout and "FINDING" not in p.stdout
+    assert "0 compiler-emitted lines mention it, 0 kernels spill" in p.stdout   # density.hip: m0 belongs to the sign words' v_writelane alone
+
+
+def test_m0_audit_tells_asm_from_compiler_code():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_audit
+    asm = ["\t;;#ASMSTART", "\ts_mov_b32 m0, s12", "\tv_writelane_b32 v30, vcc_lo, m0", "\t;;#ASMEND"]
+    bad, n = isa_audit.m0_outside_asm("\n".join(["k:"] + asm + ["\tv_add_f32_e32 v0, v0, v1 ; m0 in a comment", "\ts_endpgm"]))
+    assert not bad and n == 2
+    bad, n = isa_audit.m0_outside_asm("\n".join(["k:"] + asm + ["\ts_mov_b32 m0, s4", "\tds_read_b32 v1, v2", "\ts_endpgm"]))
+    assert bad == ["s_mov_b32 m0, s4"] and n == 2
 
 
 def test_audit_follows_control_flow_and_still_catches_a_touch():

@@ -276,6 +276,35 @@ def sgpr_hazards(name, lines):
     return problems
 
 
+def m0_outside_asm(text):
+    """density.hip's sign words go into a register pair by v_writelane with the lane select in m0 (two SGPR operands in one VOP3 break gfx9's
+    constant-bus rule), named as a clobber although hipcc calls it reserved: legal only while NOTHING the compiler emits in those kernels reads
+    or writes m0.  Returns the compiler-emitted lines that mention m0, and the number of asm lines that do."""
+    inside, bad, n_asm = False, [], 0
+    for line in text.splitlines():
+        code = line.split(";")[0] if not line.strip().startswith(";;#") else line
+        if ";;#ASMSTART" in line:
+            inside = True
+        elif ";;#ASMEND" in line:
+            inside = False
+        elif re.search(r"\bm0\b", code):
+            if inside:
+                n_asm += 1
+            else:
+                bad.append(line.strip())
+    return bad, n_asm
+
+
+def audit_density():
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "density.s")
+        compile_asm(path, os.path.join(vt_build.CSRC, "density.hip"))
+        text = open(path).read()
+    bad, n_asm = m0_outside_asm(text)
+    spills = [m.group(0) for m in re.finditer(r"\.vgpr_spill_count:\s+(\d+)", text) if int(m.group(1))]
+    return bad, n_asm, spills
+
+
 def main():
     keep = sys.argv[sys.argv.index("--keep") + 1] if "--keep" in sys.argv else None
     text = ""
@@ -300,6 +329,12 @@ def main():
             bad.append("scratch in use: %s" % m.group(0))
     if n_async == 0:
         bad.append("no kernel with asm loads found")
+    m0_lines, n_m0, dens_spills = audit_density()
+    print("density.hip: %d asm lines use m0, %d compiler-emitted lines mention it, %d kernels spill" % (n_m0, len(m0_lines), len(dens_spills)))
+    bad += ["density.hip: the compiler touches m0: %s" % l for l in m0_lines]
+    bad += ["density.hip: VGPR spills (scratch reloads wait on vmcnt(0): behind every store of the walk): %s" % x for x in dens_spills]
+    if n_m0 == 0:
+        bad.append("density.hip: no asm statement with m0 found (the audit lost its subject)")
     for b in bad:
         print("FINDING:", b)
     return 1 if bad else 0
