@@ -285,6 +285,10 @@ __global__ __launch_bounds__(64 * kWavesPerWg, ONCE ? 3 : 4) void emit_kernel(Bl
             ++n_blocks_done;
             VTMC_WAVE_SYNC();
             store_tile(tile_of(L), pre);
+            if (ablate & 128) {   // diagnostic builds: the tile's 20 ds_write_b32 a second time (same values: results stay right) -- the difference is what
+                VTMC_WAVE_SYNC();  // they cost, i.e. the most a fetch straight into LDS (LDS-DMA) could save
+                store_tile(tile_of(L), pre);
+            }
             const int far_entry = collect_async();
             if (nxt.b >= 0) load_rows_async(reinterpret_cast<const char *>(sp.base + nxt.origin), nxt.mask, pre);
             request_async();
