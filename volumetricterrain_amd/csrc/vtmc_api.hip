@@ -1086,8 +1086,17 @@ int32_t vtmc_density_fill_device_async(vtmc_ctx *ctx, const vtmc_density_params 
         ctx->h_origins_bytes = org_bytes;
     }
     memcpy(ctx->h_origins, origins, org_bytes);
-    VTMC_HIP(ctx, hipMemcpyAsync(ctx->origins.p, ctx->h_origins, org_bytes, hipMemcpyHostToDevice, st));
-    VTMC_HIP(ctx, hipEventRecord(ctx->ev_origins, st));
+    // Pinned staging never rides the context's own-queue stream (a CU-mask stream with pinned copies on it hung a C++ host at process exit,
+    // profiles/r05/stream_overlap.txt): the ordinary stream carries the upload, behind the previous fill (which still reads the previous
+    // origins) and ahead of this one, by events.
+    hipStream_t up = st;
+    if (ctx->queue_stream && st == ctx->queue_stream) {
+        up = ctx->stream;
+        if (ctx->fill_timed) VTMC_HIP(ctx, hipStreamWaitEvent(up, ctx->ev_fill[1], 0));
+    }
+    VTMC_HIP(ctx, hipMemcpyAsync(ctx->origins.p, ctx->h_origins, org_bytes, hipMemcpyHostToDevice, up));
+    VTMC_HIP(ctx, hipEventRecord(ctx->ev_origins, up));
+    if (up != st) VTMC_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_origins, 0));
     ctx->origins_upload_pending = true;
     DensityLaunch dl{};
     dl.frequency = params->frequency;
