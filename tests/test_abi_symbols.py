@@ -30,6 +30,43 @@ def test_library_exports_every_declared_symbol():
     assert lib.vtmc_version().decode().startswith("vtmc ") and "gfx950" in lib.vtmc_version().decode()
 
 
+def test_header_is_plain_c_and_a_c_program_links_the_library(tmp_path):
+    """The boundary is a C ABI: include/vtmc.h compiles as pedantic C99 (and as C++11), and a C program linked against libvtmc.so calls
+    through it -- the entry points that need no GPU: the version string, the record size, a null context answered with a status code."""
+    import shutil
+    import subprocess
+    import volumetricterrain_amd as vt
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not installed")
+    vt.load()
+    src = tmp_path / "c_host.c"
+    src.write_text("""
+#include "vtmc.h"
+#include <stdio.h>
+#include <string.h>
+int main(void)
+{
+    vtmc_triangle t;
+    memset(&t, 0, sizeof t);
+    if (sizeof t != 76 || (char *)&t.block - (char *)&t != 72) return 2;      /* CSTriangle, VoxelTerrain.cs:23-37 */
+    if (strncmp(vtmc_version(), "vtmc ", 5) != 0) return 3;
+    if (vtmc_extract_blocks(NULL, NULL, 0, NULL) != VTMC_ERR_INVALID_ARG) return 4;   /* a status code, never a crash */
+    if (vtmc_destroy(NULL) != VTMC_OK) return 5;
+    puts(vtmc_version());
+    return 0;
+}
+""")
+    inc = os.path.join(ROOT, "include")
+    lib = vt.library_path()
+    exe = tmp_path / "c_host"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, str(src), "-o", str(exe), lib,
+                    "-Wl,-rpath," + os.path.dirname(lib)], check=True, capture_output=True, text=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-x", "c++", "-fsyntax-only", str(src)],
+                   check=True, capture_output=True, text=True)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "gfx950" in p.stdout, (p.returncode, p.stdout, p.stderr[-500:])
+
+
 def test_code_object_is_gfx950_only():
     import subprocess
     import volumetricterrain_amd as vt
