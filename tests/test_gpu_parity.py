@@ -382,6 +382,36 @@ def test_density_sampler_matches_cpu_twin(ex, oracle_mod):
             assert np.abs(got[v][..., :dims[0]] - want).max() <= 2e-6, (octaves, v)
 
 
+@pytest.mark.parametrize("dims", [(1, 1, 1), (3, 5, 7), (64, 4, 1), (16, 16, 161), (257, 1, 9), (10, 26, 330)])
+def test_density_sampler_small_and_ragged_volumes(ex, oracle_mod, dims):
+    """Planes smaller than one workgroup (every lane past the plane's end walks the plane's last column again), a plane of exactly 256 points,
+    one of 257, a single step, walks of more than one segment (161, 330 steps): x-fastest with a guard band behind every volume that must stay
+    untouched, and the z-fastest fill bit-equal to it.  (The sign words: test_random_sampled_batches_classify_from_sign_bits.)"""
+    import ctypes
+    import torch
+    import volumetricterrain_amd as vt
+    dx, dy, dz = dims
+    n_vol, guard = 2, 37
+    orgs = [(5, 1000, 9), (2040, 3, 1)]
+    prm, oprm = vt.density_params("fbm8", 2048), oracle_mod.density_params("fbm8", 2048)
+    vs = dx * dy * dz + guard
+    d = torch.full((n_vol * vs,), -7.0, dtype=torch.float32, device="cuda")
+    ex.density_fill_device(prm, orgs, dims, (1, dx, dx * dy), vs, d.data_ptr())
+    got = d.cpu().numpy().reshape(n_vol, vs)
+    assert (got[:, dx * dy * dz:] == -7.0).all(), "the sampler wrote behind a volume"
+    dzf = torch.full((n_vol * vs,), -7.0, dtype=torch.float32, device="cuda")
+    ex.density_fill_device(prm, orgs, dims, (dy * dz, dz, 1), vs, dzf.data_ptr())
+    got_z = dzf.cpu().numpy().reshape(n_vol, vs)
+    assert (got_z[:, dx * dy * dz:] == -7.0).all()
+    for v, o in enumerate(orgs):
+        want = np.empty((dz, dy, dx), np.float32)
+        oracle_mod.lib().vto_density_fill(ctypes.byref(oprm), o[0], o[1], o[2], dx, dy, dz, 1, dx, dx * dy, oracle_mod._p(want))
+        g = got[v, :dx * dy * dz].reshape(dz, dy, dx)
+        assert np.abs(g - want).max() <= 2e-6, (dims, v)
+        gz = got_z[v, :dx * dy * dz].reshape(dx, dy, dz).transpose(2, 1, 0)
+        assert np.array_equal(gz.view(np.uint32), g.view(np.uint32)), "x-fastest and z-fastest fills differ in their bits"
+
+
 def test_config_256_full_compare(ex, oracle_mod):
     """BASELINE config[1]: 256^3 perlin3d, whole output against the oracle."""
     g = oracle_mod.density_volume("perlin3d", 256)
