@@ -16,7 +16,7 @@ extracts frame after frame would drive the library; every step still delivers it
 is that throughput; the latency of an isolated step is reported next to it (`step_latency_ms`, = --pipeline 1).
 
 --config stream2048 (BASELINE.json configs[4]): a 2048^3-cell fbm8 world (36 GB of samples) streamed
-as double-buffered batches of 128^3 chunks (two density buffers / contexts on one stream, the host a batch
+as double-buffered batches of 128^3 chunks (two density buffers / contexts, each on its own-queue stream, the host a batch
 ahead: sample(k + 1) and extract(k) are queued before batch k - 1's result is taken; the sampler leaves the samples'
 sign bits and the classify stage reads those); one step = one pass over the rank's 4096 / N chunks, sampling included.
 
