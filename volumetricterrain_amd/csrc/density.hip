@@ -365,12 +365,12 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
             for (int q = 1; q < NP; ++q) base_sum += a0p[q];
             base_sum.x -= lane_ramp;   // the ramp rides in the accumulator's start: nothing to subtract per step
         }
-        // noise_o = S_0 + fade(t) (S_1 - S_0) = a0 + b0 t + fade(t) (c + d t): three fmas per octave on top of the constant part
-        // packed: octaves 2p | 2p + 1 in the halves of one v_pk_fma_f32 (the sampler is bound by the VALU's issue slots: 61 a step in round 4,
-        // 24 of them these fmas); even and odd octaves accumulate apart and meet at the end
         // the step's row: broadcast reads (every lane the same address), AFTER the rebuild: sixteen registers a face does not have to work around
         const v4f ta = rp[0], tb = rp[1], va = rp[2], vb = rp[3];
         const v2f t2[4] = {ta.xy, ta.zw, tb.xy, tb.zw}, f2[4] = {va.xy, va.zw, vb.xy, vb.zw};
+        // noise_o = S_0 + fade(t) (S_1 - S_0) = a0 + b0 t + fade(t) (c + d t): three fmas per octave on top of the constant part, PACKED: octaves
+        // 2p | 2p + 1 in the halves of one v_pk_fma_f32 (the sampler is bound by the vector ALU's issue slots: 61 a step in round 4, 24 of them
+        // these fmas); even and odd octaves accumulate apart and meet at the end
         v2f acc = base_sum;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
@@ -386,8 +386,8 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
             if (jj % kTrSteps == kTrSteps - 1 || jj == w_count - 1) flush_transposed(jj - jj % kTrSteps, jj % kTrSteps + 1);   // workgroup-uniform
         }
     } else {
-        // The sampler is bound by ISSUED instructions like the emit kernel (a SIMD retires one per four cycles whatever its kind), and round 4's
-        // step spent ~38 of its ~62 on things that are not its 24 fmas.  Per 64 steps now: ONE ballot says which steps rebuild anything (a bit
+        // Round 4's step spent ~38 of its ~62 instructions on things that are not its 24 fmas (most of them scalar -- which, it turned out, issue
+        // beside the vector ones here: removing them bought 3.5 %, packing the fmas 11 %).  Per 64 steps now: ONE ballot says which steps rebuild anything (a bit
         // test per step instead of two readfirstlanes + or + compare, and the mask row is read only where it is needed); no exec mask around
         // the stores at all (a lane past the plane's end walks the plane's LAST column: the same value to the same address as that column's
         // own lane); a step's sign ballot goes into lane (step % 64) of a register pair (two v_writelane) and the chunk's 64 words leave in
