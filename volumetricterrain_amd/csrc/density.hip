@@ -306,8 +306,9 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
         const v2f p01 = {__builtin_fmaf(g01.y, b1, g01.x * a0), g01.w}, p11 = {__builtin_fmaf(g11.y, b1, g11.x * a1), g11.w};
         const v2f pu0 = fma2(u2, p10 - p00, p00), pu1 = fma2(u2, p11 - p01, p01);
         const v2f pv = fma2(v2, pu1 - pu0, pu0);
-        alpha = am * pv.x;
-        beta = am * pv.y;
+        const v2f ab = pv * v2f{am, am};   // one packed multiply for both
+        alpha = ab.x;
+        beta = ab.y;
     };
 
     float *dst = out + vol * dl.sv + (long long)i * dl.sx + (long long)j * dl.sy + (long long)k * dl.sz;
