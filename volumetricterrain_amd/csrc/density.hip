@@ -283,24 +283,28 @@ __global__ __launch_bounds__(256, ZT ? 3 : 4) void density_column_kernel(Density
     }
 
     // one face of the cell: the four corners over the lane axes at lattice row Wp of the walk axis,
-    // interpolated along A then B.  The inputs pass through an empty asm statement so that nothing
-    // derived from them is hoisted out of the walk for all octaves at once (~50 VGPRs otherwise).
+    // interpolated along A then B.
+    // Everything a face derives from the column's constants alone (ra - 1, rb - 1, the halves of the two keys) would be hoisted out of the walk for
+    // all octaves at once (~50 VGPRs): those six instructions are volatile asm, which stays where it is and reads the state in place (round 4
+    // passed COPIES of the state through an empty asm statement: four v_mov a face).
+    typedef const __attribute__((address_space(3))) v4f *lds_v4f;
+    const unsigned g512_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)s_g512;
     auto face = [&](const ColOct &s, int o, unsigned Wp, float am, float &alpha, float &beta) {
-        float ra = s.ra, rb = s.rb;
-        unsigned key = s.key, key2 = s.key2;
-        asm volatile("" : "+v"(ra), "+v"(rb), "+v"(key), "+v"(key2));
-        v4f g00, g01, g10, g11;   // g[a-corner][b-corner]
-        {
-            const char *g5 = reinterpret_cast<const char *>(s_g512);
-            const unsigned w16 = Wp << 4;   // wave-uniform
-            g00 = *reinterpret_cast<const v4f *>(g5 + ((key & 0xFFFFu) + w16));
-            g01 = *reinterpret_cast<const v4f *>(g5 + ((key >> 16) + w16));
-            g10 = *reinterpret_cast<const v4f *>(g5 + ((key2 & 0xFFFFu) + w16));
-            g11 = *reinterpret_cast<const v4f *>(g5 + ((key2 >> 16) + w16));
-        }
+        const float ra = s.ra, rb = s.rb;
+        float a1, b1;
+        asm volatile("v_add_f32 %0, -1.0, %2\n\tv_add_f32 %1, -1.0, %3" : "=v"(a1), "=v"(b1) : "v"(ra), "v"(rb));
+        const unsigned gw = g512_lds + (Wp << 4);   // wave-uniform: table base + 16 * lattice row
+        unsigned ad00, ad01, ad10, ad11;   // g[a-corner][b-corner]: key = 00 | 01 << 16, key2 = 10 | 11 << 16 (byte offsets of the hashes' gradients)
+        asm volatile("v_add_u32_sdwa %0, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                     "v_add_u32_sdwa %1, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                     "v_add_u32_sdwa %2, %4, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                     "v_add_u32_sdwa %3, %4, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+                     : "=&v"(ad00), "=&v"(ad01), "=&v"(ad10), "=&v"(ad11)
+                     : "s"(gw), "v"(s.key), "v"(s.key2));
+        const v4f g00 = *(lds_v4f)(uintptr_t)ad00, g01 = *(lds_v4f)(uintptr_t)ad01, g10 = *(lds_v4f)(uintptr_t)ad10, g11 = *(lds_v4f)(uintptr_t)ad11;
         const float2 uv = s_uv[o][tid];
         const v2f u2 = {uv.x, uv.x}, v2 = {uv.y, uv.y};
-        const float a0 = ra, a1 = ra - 1.0f, b0 = rb, b1 = rb - 1.0f;
+        const float a0 = ra, b0 = rb;
         // a corner = (its gradient's x-y dot product, its gradient's component along the walk): the lerps along A then B run on both at once
         const v2f p00 = {__builtin_fmaf(g00.y, b0, g00.x * a0), g00.w}, p10 = {__builtin_fmaf(g10.y, b0, g10.x * a1), g10.w};
         const v2f p01 = {__builtin_fmaf(g01.y, b1, g01.x * a0), g01.w}, p11 = {__builtin_fmaf(g11.y, b1, g11.x * a1), g11.w};
