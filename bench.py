@@ -766,12 +766,12 @@ def run_stream(args, torch, dist):
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         # the sampler's own bound is the vector ALU's issue slots.  Vector instructions per sample, counted in the kernel's ISA (DESIGN.md 4,
         # profiles/r05/sampler_valu_bound.txt): 3 packed fmas per octave PAIR + 7 for the step (sum, sign compare, two v_writelane for the sign
-        # word, store address, LDS address, one spare); a rebuilt octave is 27 (a face 22: 4 addresses, 2 + 8 for the corner dot products, 6 packed
-        # lerps, 2 amplitude; 5 for the derived constants), at f * lacunarity^o rebuilds per sample and octave; a step with any rebuild costs 7
-        # (mask words to scalars, the constants' sum); a walk starts with two faces per octave and ~25 per octave of column set-up.  The counter
-        # (SQ_INSTS_VALU) reads 43 per sample for config 5, this model 39.
+        # word, store address, LDS address, one spare); a rebuilt octave is 26 (a face 21: 4 addresses, 2 + 8 for the corner dot products, 6 packed
+        # lerps, 1 packed amplitude; 5 for the derived constants), at f * lacunarity^o rebuilds per sample and octave; a step with any rebuild
+        # costs 7 (mask words to scalars, the constants' sum); a walk starts with two faces per octave and ~25 per octave of column set-up.
+        # The counter (SQ_INSTS_VALU) read 43 per sample for config 5 before the last two trims (-3), this model says 38.
         rates = [min(1.0, st.params.frequency * (st.params.lacunarity ** o)) for o in range(octaves)]
-        lane_ops = samples * (1.5 * octaves + 7.0 + 27.0 * sum(rates) + 7.0 * max(rates) + (2 * 27.0 + 25.0) * octaves / st.dim)
+        lane_ops = samples * (1.5 * octaves + 7.0 + 26.0 * sum(rates) + 7.0 * max(rates) + (2 * 26.0 + 25.0) * octaves / st.dim)
         sampler_flops = samples * (2.0 * 3.0 * octaves + 2.0 * 34.0 * sum(rates))   # the arithmetic itself: 3 fmas per octave and sample, ~34 flop-pairs a face
         out = {
             "metric": "streamed sampler + marching-cubes extraction throughput on a %d^3 %s world (Mvoxels/s)" % (n, args.kind),
