@@ -49,6 +49,7 @@ GPU_ORDER = [
     r"test_tuning_matrix\.py",
     r"test_gpu_parity\.py::test_rccl",
     r"test_bench_modes\.py",
+    r"test_own_queue_cpp_host\.py",     # last: a plain C++ process on ROCm's own runtime; a hang there costs nothing that ran before it
 ]
 _GPU_ORDER = [re.compile(p) for p in GPU_ORDER]
 
