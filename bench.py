@@ -10,8 +10,8 @@ the world stays 1024^3, chunk c belongs to rank c % N (64 chunks each at N = 8),
 with the path's one collective, the RCCL all-gather of per-chunk {vertices, triangles} over xGMI
 (vtmc_allgather_volume_counts, queued on the extract's stream; --scaling weak keeps 512 chunks per
 rank on a 1024 x 1024 x 1024*N world instead).  Steps are independent passes over the same resident input and
-run two deep by default (--pipeline 2): two contexts take turns and step k + 1 is queued before the host takes
-step k's T and offsets, so the device goes from step to step without waiting for the host -- the way a host that
+run four deep by default (--pipeline 4): four contexts take turns, each on its own-queue stream, and step k + 3 is queued before the host
+takes step k's T and offsets, so the device goes from step to step without waiting for the host -- the way a host that
 extracts frame after frame would drive the library; every step still delivers its T, gather and offsets.  `value`
 is that throughput; the latency of an isolated step is reported next to it (`step_latency_ms`, = --pipeline 1).
 
@@ -71,13 +71,15 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chunks", type=int, default=32, help="chunks the CPU oracle is timed on")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0: physical cores in this process's CPU share, at most 16 per GPU)")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
-                    help="grid1024: steps in flight.  2 (default): two contexts take turns, step k + 1 is queued before the host takes step "
-                         "k's result -- the device never waits for the host.  At N > 1 both contexts issue their all-gather through ONE "
-                         "communicator (vtmc_comm_share), behind the emit kernel on the one stream everything runs on: for RCCL the same as a "
-                         "single context.  1: every step ends with its host wait (the latency of an isolated step, also reported as step_latency_ms)")
+    ap.add_argument("--pipeline", type=int, default=4, choices=[1, 2, 3, 4],
+                    help="grid1024: steps in flight = contexts taking turns (each with its own result buffers); step k + d - 1 is queued before the "
+                         "host takes step k's result -- the device never waits for the host.  Default 4 (rounds 2-5a: 2): in ONE process, "
+                         "alternating, 4 in flight run a rank's step of an 8-rank run 8 %% faster than 2 (0.2154 against 0.2341 ms with the collective "
+                         "and the host's read-back in the loop) and the whole 1024^3 step 1-2 %% (tools/depth_probe.py, profiles/r05/depth_probe.txt).  "
+                         "At N > 1 all contexts issue their all-gather through ONE communicator (vtmc_comm_share).  1: every step ends with its host "
+                         "wait (the latency of an isolated step, also reported as step_latency_ms)")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
-                    help="grid1024, --pipeline 2: HIP streams the two contexts queue their steps on.  2 (default): a stream each -- step k + 1's "
+                    help="grid1024, --pipeline > 1: HIP streams the contexts queue their steps on.  2 (default): a stream EACH (its own-queue stream) -- step k + 1's "
                          "classify kernel starts on the CUs step k's emit kernel leaves as it drains (the emit kernel is bound by issued "
                          "instructions, the classify kernel by memory: profiles/r05/rank_overlap_probe.txt: -4 %% of a step at N = 1, -20 %% of a "
                          "rank's step of an 8-rank run); 1: one stream for both (rounds 2-4)")
@@ -376,7 +378,7 @@ def run_grid(args, torch, dist):
         for e in exs:
             e.set_tuning(**kv)
     # the contexts' streams (vtmc_context_stream; --streams 2: the ones on a hardware queue of their own -- ordinary HIP streams may share a
-    # queue and then run strictly in turn), wrapped for torch's copies and events: one per context in flight (--streams 2: the steps of the two contexts
+    # queue and then run strictly in turn), wrapped for torch's copies and events: one per context in flight (--streams 2: the steps of the contexts
     # overlap where one kernel drains and the next ramps up), or the first context's for everything (--streams 1)
     # (never torch's CURRENT stream: what torch allocates while a stream is current belongs to that stream in its caching allocator, and
     # these streams die with their contexts -- torch work is put on them with `with torch.cuda.stream(...)` only where it must be)
@@ -522,7 +524,7 @@ def run_grid(args, torch, dist):
     ms_per_step = elapsed / args.steps * 1e3
     # The kernels' own durations.  With a stream per context the HIP events around a kernel also see the time it waits for CUs beside the
     # other context's kernels (a classify kernel "takes" 1.9 ms there): the roofline of a KERNEL needs it alone on the chip.  A second
-    # region of the same K steps, the same two contexts taking turns, both on the first context's stream (rounds 1-4's timed region).
+    # region of the same K steps, the same contexts taking turns, all on the first context's stream (rounds 1-4's timed region, two contexts then).
     live = {k: v / max(stage_steps[0], 1) for k, v in stage_acc.items()}
     serial_ms_per_step = ms_per_step
 
@@ -579,7 +581,7 @@ def run_grid(args, torch, dist):
         roofline = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes": alg[dom], "avg_ms": round(avg[dom], 4)}
-        roofline["measured"] = ("HIP events on the kernels' stream over %d steps, two contexts taking turns on ONE stream" % args.steps) + (
+        roofline["measured"] = ("HIP events on the kernels' stream over %d steps, the contexts taking turns on ONE stream" % args.steps) + (
             "" if len(streams) == 1 else " -- a second region behind the timed one (%.4f ms per step there): in the timed region the contexts have a "
             "stream each and a kernel's events also see the time it shares the chip with the other context's kernels, see kernels.*.two_queue_span_ms" % serial_ms_per_step)
         per_kernel = {k: {"avg_ms": round(avg[k], 4), "alg_GBps": round(alg[k] / (avg[k] * 1e-3) / 1e9, 1) if avg[k] > 0 else None,

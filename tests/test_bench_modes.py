@@ -32,7 +32,7 @@ def test_single_gpu_line_carries_roofline_and_reproducible_cpu_leg():
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["kernel"] in ("classify_kernel", "emit_kernel") and 0 < r["frac"] < 1
     assert "traffic_source" in r
-    assert j["pipeline_depth"] == 2 and j["streams"] == 2 and j["step_latency_ms"] > 0      # throughput with two steps in flight on a stream each, isolated-step latency beside it
+    assert j["pipeline_depth"] == 4 and j["streams"] == 4 and j["step_latency_ms"] > 0      # throughput with four steps in flight on a stream each, isolated-step latency beside it
     assert "ONE stream" in r["measured"] and all(k["isolated_step_ms"] > 0 and k["two_queue_span_ms"] >= k["avg_ms"] * 0.8 for k in j["kernels"].values())
     assert j["one_stream_ms_per_step"] > 0
     assert j["path_roofline"]["step_ms"] == j["ms_per_step"]
@@ -57,7 +57,7 @@ def test_strong_scaling_two_ranks_on_one_device():
     assert j["config"]["chunks_per_gpu"] == 4 and "c -> rank c % 2" in j["config"]["workload"]
     assert abs(j["triangles_total"] - 2655156) < 2000 and 0 < j["triangles_rank0"] < j["triangles_total"]
     assert j["allgather_ms"]["avg"] >= 0 and j["cpu_baseline"] is None
-    assert j["pipeline_depth"] == 2   # two contexts take turns; at N > 1 they share one communicator (vtmc_comm_share)
+    assert j["pipeline_depth"] == 4   # four contexts take turns; at N > 1 they share one communicator (vtmc_comm_share)
 
 
 def test_stream_config_line():
@@ -78,13 +78,13 @@ def test_exchange_path_through_a_world_of_one_communicator():
             {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j["n_gpus"] == 1 and abs(j["triangles_total"] - 2655156) < 2000
     assert j["allgather_ms"] is not None and j["allgather_ms"]["avg"] >= 0
-    assert j["streams"] == 2 and "extract's stream" in j["config"]["collective"]     # the default: a stream per context, a step's collective behind its emit kernel (the library chains the communicator's collectives)
+    assert j["streams"] == 4 and "extract's stream" in j["config"]["collective"]     # the default: a stream per context, a step's collective behind its emit kernel (the library chains the communicator's collectives)
     j0 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--streams", "1"],
              {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j0["streams"] == 1 and "extract's stream" in j0["config"]["collective"] and j0["triangles_total"] == j["triangles_total"]
     j3 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--gather-stream", "side"],
              {"VTMC_BENCH_FORCE_COMM": "1"})
-    assert j3["streams"] == 2 and "second stream" in j3["config"]["collective"] and j3["triangles_total"] == j["triangles_total"]
+    assert j3["streams"] == 4 and "second stream" in j3["config"]["collective"] and j3["triangles_total"] == j["triangles_total"]
     j1 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--pipeline", "1"],
              {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j1["pipeline_depth"] == 1 and j1["streams"] == 1 and j1["triangles_total"] == j["triangles_total"]
