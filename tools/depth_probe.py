@@ -17,7 +17,7 @@ n, c, dim = 1024, 128, 130
 W = int(next((a for a in sys.argv[1:] if a.isdigit()), "1"))
 rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 5
 K = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 40
-D = 4
+D = int(sys.argv[sys.argv.index("--max") + 1]) if "--max" in sys.argv else 4
 exs = [vt.Extractor(0) for _ in range(D)]
 sp = [e.stream_handle(own_queue=True) for e in exs]
 org = sharding.chunk_origins(n, c, 0, W)
