@@ -90,3 +90,12 @@ for _ in range(rounds):
 print("rank 0 of %d: %d chunks, T = %d per step; ms per step, two steps in flight, %d rounds of 200 steps per mode (alternating)" % (W, len(org), T0, rounds))
 for name, _ in MODES:
     print("  %-75s %s   min %.4f" % (name, " ".join("%.4f" % x for x in res[name]), min(res[name])))
+# torch objects that touched the contexts' streams (events, pinned tensors: PyTorch records an event on the stream when it frees one) go before
+# the contexts -- left to the interpreter's tear-down they outlive the streams and the process dies in the HIP runtime
+torch.cuda.synchronize()
+del evs, gh, g, d, s1, s2, s3
+import gc  # noqa: E402
+gc.collect()
+torch.cuda.empty_cache()
+for e in reversed(exs):   # the borrower of the communicator first
+    e.close()
