@@ -141,13 +141,18 @@ int32_t vtmc_extract_volumes_device(vtmc_ctx *ctx, const vtmc_volume_batch *batc
 int32_t vtmc_extract_volumes_device_async(vtmc_ctx *ctx, const vtmc_volume_batch *batch, void *stream, uint32_t flags);
 int32_t vtmc_extract_finish(vtmc_ctx *ctx, int64_t *tri_count);
 
-/* A stream of the context (a hipStream_t), valid until vtmc_destroy.  own_queue = 0: the context's own stream, what `stream` = NULL means
- * everywhere above.  own_queue = 1: a second stream that sits on a HARDWARE QUEUE OF ITS OWN (made on first request): ordinary HIP streams
- * share a handful of hardware queues, and two contexts whose streams land on one queue run their steps strictly in turn; a host that keeps
- * two steps in flight passes each context's own-queue stream to vtmc_extract_volumes_device_async and the steps overlap where one kernel
- * drains and the next ramps up (bench.py --streams 2).  Measured under PyTorch's HIP 7.0 runtime; see INTEGRATION.md ("Streams") for what a
- * plain C++ host linked against ROCm 7.2 showed.  (The reference has one queue: every Dispatch / GetData of BatchUpdate is in program order
- * on Unity's graphics device, VoxelTerrain.cs:365-427.) */
+/* A stream of the context (a hipStream_t).  own_queue = 0: the context's own stream, what `stream` = NULL means everywhere above.
+ * own_queue = 1: a second stream that sits on a HARDWARE QUEUE OF ITS OWN (taken on first request): ordinary HIP streams share a handful
+ * of hardware queues, and two contexts whose streams land on one queue run their steps strictly in turn; a host that keeps several steps
+ * in flight passes each context's own-queue stream to vtmc_extract_volumes_device_async and the steps overlap where one kernel drains and
+ * the next ramps up (bench.py --streams 2).
+ * LIFETIME: the context stops using the stream at vtmc_destroy (which drains it), but the HANDLE stays valid until the process exits: the
+ * library never destroys a stream, it parks it and gives it to the next context created on that device.  Host-side objects that still refer
+ * to it after vtmc_destroy -- events recorded on it, a framework's stream wrapper, a caching allocator that records on it when it frees a
+ * pinned buffer -- are therefore safe, whatever order they are released in.  Work the HOST queues on the handle after vtmc_destroy simply
+ * shares the stream with that next context.  See INTEGRATION.md ("Streams").
+ * (The reference has one queue: every Dispatch / GetData of BatchUpdate is in program order on Unity's graphics device,
+ * VoxelTerrain.cs:365-427.) */
 int32_t vtmc_context_stream(vtmc_ctx *ctx, int32_t own_queue, void **stream);
 
 /* Device pointers to the results of the last extract_* (valid until the next extract_* / destroy):
@@ -335,10 +340,14 @@ int32_t vtmc_comm_unique_id(uint8_t id[VTMC_COMM_ID_BYTES]);
 int32_t vtmc_comm_init_rank(vtmc_ctx *ctx, const uint8_t id[VTMC_COMM_ID_BYTES], int32_t rank, int32_t world_size);
 int32_t vtmc_comm_destroy(vtmc_ctx *ctx);
 
-/* `ctx` uses the communicator of `owner` (same device, same process) for vtmc_allgather_volume_counts from now on: two contexts that take
- * turns on ONE stream (a step in flight while the host takes the previous one) then issue all their collectives through one communicator,
- * in stream order -- nothing for RCCL that a single context does not already do.  `ctx` never destroys the communicator; `owner` must
- * stay alive, and keep it, as long as `ctx` uses it (vtmc_comm_destroy(ctx) or another vtmc_comm_* call on ctx ends the sharing). */
+/* `ctx` uses the communicator of `owner` (same device, same process) for vtmc_allgather_volume_counts from now on: contexts that take
+ * turns (a step in flight while the host takes the previous one) issue all their collectives through ONE communicator.  ORDER: the
+ * collectives of a communicator -- its owner's and every borrower's -- form one chain kept by the owner: a collective queued on another
+ * stream than the one before it first waits, on the device, for the previous one's event, so RCCL sees them one after the other, in host
+ * call order, exactly as on one stream -- and that order must be the same on every rank.  ONE HOST THREAD drives all contexts that share a
+ * communicator (the chain's state on the owner is updated by the borrowers without a lock); contexts with communicators of their own may
+ * live on different threads.  `ctx` never destroys the communicator; `owner` must stay alive, and keep it, as long as `ctx` uses it
+ * (vtmc_comm_destroy(ctx) or another vtmc_comm_* call on ctx ends the sharing; an owner that goes first detaches its borrowers). */
 int32_t vtmc_comm_share(vtmc_ctx *ctx, vtmc_ctx *owner);
 
 /* All-gather of volume_counts of the last extract_* on `stream` (NULL = the context's stream),
@@ -348,8 +357,8 @@ int32_t vtmc_comm_share(vtmc_ctx *ctx, vtmc_ctx *owner);
  * Queued behind vtmc_extract_volumes_device_async (before vtmc_extract_finish) whose chunks are whole
  * scan tiles (a multiple of 2048 blocks, e.g. 128^3 cells), the counts have already left the scan
  * kernel: the collective then runs on the context's second stream BESIDE the emit kernel (launched a
- * workgroup per XCD short for it) and `stream` merely waits for its end (tuning key "gather_beside",
- * default 1).  Otherwise it runs on `stream`, behind the emit kernel. */
+ * workgroup per XCD short for it) and `stream` merely waits for its end -- only with the tuning key "gather_beside" = 1
+ * (default 0).  Otherwise, and by default, it runs on `stream`, behind the emit kernel. */
 int32_t vtmc_allgather_volume_counts(vtmc_ctx *ctx, uint32_t *d_all_counts, int32_t volumes_per_rank, void *stream);
 
 /* Blocking device -> host copy on `stream` (NULL = the context's stream) through the library's own

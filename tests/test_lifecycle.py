@@ -192,3 +192,51 @@ def test_the_owner_of_a_shared_communicator_goes_first(oracle_mod):
     finally:
         owner.close()       # owner first, on purpose
         borrower.close()
+
+
+def test_torch_objects_on_a_contexts_stream_may_outlive_the_context(oracle_mod):
+    """Round 5's aborts (rc 134 in the interpreter's tear-down): a pinned tensor that was copied on a stream from vtmc_context_stream, an event
+    recorded on it or the ExternalStream wrapper outlived the context, whose destruction destroyed the stream -- PyTorch records an event on
+    the stream when it FREES such a tensor.  Since round 6 the library parks its streams instead of destroying them (the handle stays valid
+    until the process exits): everything here is released AFTER close(), in the worst order, and the next context gets the parked stream."""
+    import gc
+
+    import torch
+    import volumetricterrain_amd as vt
+    c, dim = 32, 34
+    g = oracle_mod.density_volume("perlin3d", c)
+    want = oracle_mod.extract_grid(g, count_only=True)[0]
+    d = torch.from_numpy(np.ascontiguousarray(g.transpose(2, 1, 0))).cuda()
+    handles = []
+    for own_queue in (True, False):
+        ex = vt.Extractor(0)
+        h = ex.stream_handle(own_queue=own_queue)
+        handles.append(h)
+        st = torch.cuda.ExternalStream(h)
+        ex.extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 1, dim ** 3, st.cuda_stream)
+        dev = torch.zeros(64, dtype=torch.int32, device="cuda")
+        pinned = torch.zeros(64, dtype=torch.int32).pin_memory()
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(st):
+            dev.add_(1)                                  # torch work behind the queued step, on the context's stream
+            pinned.copy_(dev, non_blocking=True)         # the caching host allocator now ties `pinned` to this stream
+        ev.record(st)
+        assert ex.extract_finish() == want
+        ex.close()                                       # the context goes FIRST; its stream is drained and parked
+        ev.synchronize()                                 # ... and every torch object that refers to it is used and released afterwards
+        assert int(pinned[0]) == 1
+        del pinned                                       # freeing it records an event on the (parked) stream
+        gc.collect()
+        ev2 = torch.cuda.Event()
+        ev2.record(st)                                   # the handle is still a stream
+        ev2.synchronize()
+        del ev, ev2, st, dev
+        gc.collect()
+        torch.cuda.empty_cache()
+    # a new context on this device takes the parked own-queue stream instead of making another one
+    ex = vt.Extractor(0)
+    try:
+        assert ex.stream_handle(own_queue=True) == handles[0]
+        assert ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 1, dim ** 3, ex.stream_handle(own_queue=True)) == want
+    finally:
+        ex.close()

@@ -78,3 +78,52 @@ def test_chunk_ownership_is_a_partition():
         assert np.array_equal(merged, all_o)
     with pytest.raises(ValueError):
         sharding.chunk_grid(100, 32)
+
+
+def test_balanced_assignment_is_a_partition_evener_than_modulo_and_the_same_on_every_rank(oracle_mod):
+    """Round 6: the chunks of a strong-scaling run are cut again by the counts every rank holds after the first all-gather.  512 chunks of a
+    perlin3d world (256^3 as 32^3-cell chunks here), counts from the oracle: a partition with equal chunk numbers, never less even than c % N,
+    a pure function of the counts (so every rank derives the same lists), and the slot permutation puts every chunk where its rank sent it."""
+    from volumetricterrain_amd import sharding
+    n, chunk = 256, 32
+    costs = []
+    for o in sharding.chunk_origins(n, chunk):
+        g = oracle_mod.density_volume("perlin3d", n, origin=tuple(int(v) for v in o), dims=(chunk + 2,) * 3)
+        costs.append(oracle_mod.extract_grid(g, count_only=True)[0])
+    costs = np.array(costs)
+    assert len(costs) == 512 and costs.sum() > 0
+    for world in (2, 4, 8, 3):
+        a = sharding.balanced_assignment(costs, world)
+        assert sorted(c for part in a for c in part) == list(range(512))
+        cap = -(-512 // world)
+        assert all(len(part) <= cap for part in a) and all(part == sorted(part) for part in a)
+        assert a == sharding.balanced_assignment(list(costs), world)
+        m, b = sharding.imbalance(costs, sharding.modulo_assignment(512, world)), sharding.imbalance(costs, a)
+        assert 1.0 <= b <= m + 1e-12
+        if world == 8:
+            assert b < 1.005 < m          # c % 8 leaves percents on the table, the greedy cut per mills
+        perm = sharding.slot_permutation(a, cap)
+        gathered = np.zeros(world * cap, np.int64)
+        for r, part in enumerate(a):
+            gathered[r * cap:r * cap + len(part)] = costs[part]
+        assert np.array_equal(gathered[perm], costs)
+    assert np.array_equal(sharding.origins_of(n, chunk, range(512)), sharding.chunk_origins(n, chunk))
+    assert np.array_equal(sharding.origins_of(n, chunk, sharding.owned_chunks(512, 3, 8)), sharding.chunk_origins(n, chunk, 3, 8))
+
+
+def test_stream_cpu_sample_is_stratified_by_triangle_counts():
+    """bench.py's pick for the CPU leg of config 5: a terrain world has its surface in a fifth of its chunks; an evenly spread sample of 8 of 4096
+    missed it altogether in round 5 (triangles_in_sample = 0).  The pick must contain surface chunks and match the world's triangles per chunk."""
+    import bench
+    rng = np.random.default_rng(7)
+    counts = np.zeros(4096, np.int64)
+    surface = rng.choice(4096, 600, replace=False)
+    counts[surface] = rng.integers(40000, 260000, len(surface))
+    for n_sample in (8, 16, 5):
+        idx = bench.pick_representative_chunks(counts, n_sample)
+        assert len(idx) == n_sample and len(set(idx)) == n_sample and all(0 <= i < 4096 for i in idx)
+        ratio = counts[idx].mean() / counts.mean()
+        assert counts[idx].sum() > 0 and 0.8 < ratio < 1.2, ratio
+    assert bench.pick_representative_chunks(np.zeros(10, np.int64), 4) and len(bench.pick_representative_chunks(counts[:3], 8)) == 3
+    full = np.full(64, 1000, np.int64)
+    assert len(bench.pick_representative_chunks(full, 8)) == 8      # no empty chunks at all: every pick is a surface chunk

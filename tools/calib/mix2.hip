@@ -11,6 +11,10 @@
 // Every variant is timed over `reps` launches with hipEvents; bytes are the algorithmic ones (reads + writes).
 // Output: one JSON object per line.
 //
+// `mix2 <GiB> box` (round 6): the four numbers bench.py puts next to its kernels' rates -- what THIS box's memory delivers for a plain
+// read stream, a plain write stream, a plain copy and a 4 : 7 read : write mix (the emit kernel moves 1.85 GB in and 3.26 GB out: 36 : 64),
+// each the best of a few launch shapes, median of 5 launches; about 60 ms of kernels, one JSON line.
+//
 //   hipcc -O3 --offload-arch=gfx950 -o mix2 mix2.hip && ./mix2 [GiB of buffer, default 4]
 #include <hip/hip_runtime.h>
 
@@ -342,6 +346,52 @@ int main(int argc, char **argv)
     CK(hipMalloc(&buf, total_f4 * 16));
     CK(hipMemset(buf, 0, total_f4 * 16));
     const int reps = 7;
+
+    if (argc > 2 && !strcmp(argv[2], "box")) {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        const int r5 = 5;
+        auto median_ms = [&](auto launch) {
+            std::vector<float> ms(r5);
+            for (int i = 0; i < r5 + 1; ++i) {
+                CK(hipEventRecord(e0));
+                launch();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                if (i) CK(hipEventElapsedTime(&ms[i - 1], e0, e1));
+            }
+            std::sort(ms.begin(), ms.end());
+            return (double)ms[r5 / 2];
+        };
+        const long long n = total_f4;
+        const unsigned g1 = (unsigned)((n + 255) / 256);
+        // plain read / write over the whole buffer, plain copy half -> half (one float4 per thread; and the persistent U = 4 shapes)
+        double rd = (double)n * 16.0 / median_ms([&] { hipLaunchKernelGGL(read_plain_kernel, dim3(g1), dim3(256), 0, 0, buf, buf, n); }) / 1e9;
+        rd = std::max(rd, (double)n * 16.0 / median_ms([&] { hipLaunchKernelGGL((mix_kernel<1, 0, 4, false>), dim3(4 * n_cus), dim3(256), 0, 0, buf, buf, n); }) / 1e9);
+        double wr = (double)n * 16.0 / median_ms([&] { hipLaunchKernelGGL(write_plain_kernel, dim3(g1), dim3(256), 0, 0, buf, n); }) / 1e9;
+        wr = std::max(wr, (double)n * 16.0 / median_ms([&] { hipLaunchKernelGGL((mix_kernel<0, 1, 4, false>), dim3(4 * n_cus), dim3(256), 0, 0, buf, buf, n); }) / 1e9);
+        const long long h = n / 2;
+        double cp = 2.0 * h * 16.0 / median_ms([&] { hipLaunchKernelGGL((copy_plain_kernel<1>), dim3((unsigned)((h + 255) / 256)), dim3(256), 0, 0, buf, buf + h, h); }) / 1e9;
+        cp = std::max(cp, 2.0 * h * 16.0 / median_ms([&] { hipLaunchKernelGGL((copy_plain_kernel<4>), dim3((unsigned)((h + 1023) / 1024)), dim3(256), 0, 0, buf, buf + h, h); }) / 1e9);
+        const long long u = n / 11;   // 4 read streams + 7 write streams of u float4 each
+        double mx = 0.0;
+        mx = std::max(mx, 11.0 * u * 16.0 / median_ms([&] { hipLaunchKernelGGL((mix_kernel<4, 7, 2, false>), dim3(4 * n_cus), dim3(256), 0, 0, buf, buf + 4 * u, u); }) / 1e9);
+        mx = std::max(mx, 11.0 * u * 16.0 / median_ms([&] { hipLaunchKernelGGL((mix_kernel<4, 7, 4, false>), dim3(4 * n_cus), dim3(256), 0, 0, buf, buf + 4 * u, u); }) / 1e9);
+        mx = std::max(mx, 11.0 * u * 16.0 / median_ms([&] { hipLaunchKernelGGL((mix_kernel<4, 7, 4, false>), dim3(2 * n_cus), dim3(256), 0, 0, buf, buf + 4 * u, u); }) / 1e9);
+        mx = std::max(mx, 11.0 * u * 16.0 / median_ms([&] { hipLaunchKernelGGL((mix_kernel<4, 7, 8, false>), dim3(2 * n_cus), dim3(256), 0, 0, buf, buf + 4 * u, u); }) / 1e9);
+        // the emit kernel's own access shape (40-byte rows gathered, 76-byte records streamed), without its arithmetic
+        const long long dst_f4 = n * 3 / 4, src_floats = (n - dst_f4) * 4, n_steps = dst_f4 / 608;
+        const float *src = reinterpret_cast<const float *>(buf + dst_f4);
+        double es = 0.0;
+        for (int per_cu : {4, 8})
+            es = std::max(es, (double)n_steps * (608.0 * 16 + 64 * 40) / median_ms([&] { hipLaunchKernelGGL(emit_shape_kernel, dim3(per_cu * n_cus), dim3(256), 0, 0, src, src_floats, buf, n_steps); }) / 1e9);
+        printf("{\"kernel\": \"box\", \"GiB\": %.2f, \"read_TBps\": %.3f, \"write_TBps\": %.3f, \"copy_TBps\": %.3f, \"mix_4r7w_TBps\": %.3f, \"emit_shape_TBps\": %.3f, "
+               "\"cus\": %d, \"device\": \"%s\"}\n", gib, rd, wr, cp, mx, es, n_cus, prop.name);
+        fflush(stdout);
+        CK(hipFree(buf));
+        return 0;
+    }
 
     if (argc > 2 && !strcmp(argv[2], "dword")) {
         const float *src = reinterpret_cast<const float *>(buf);

@@ -228,7 +228,7 @@ int32_t vtmc_allgather_volume_counts(vtmc_ctx *ctx, uint32_t *d_all_counts, int3
     // extract's emit launch (whose first workgroup may be the one that writes the per-volume counts)
     if (!beside && ctx->pending.active && ctx->pending.launched && st != ctx->pending.stream) VTMC_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[3], 0));
     if (beside) {
-        if (!ctx->comm_stream) VTMC_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+        if (!ctx->comm_stream) VTMC_HIP(ctx, take_stream(ctx->device, false, ctx->n_cus, &ctx->comm_stream));
         if (!ctx->ev_gather) VTMC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_gather, hipEventDisableTiming));
         gs = ctx->comm_stream;
         VTMC_HIP(ctx, hipStreamWaitEvent(gs, ctx->ev[2], 0));

@@ -18,7 +18,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -34,6 +36,68 @@ constexpr int kStageTrimAfter = 8;   // an over-sized staging buffer goes after 
 }  // namespace
 
 namespace vtmc {
+
+// STREAMS OUTLIVE THEIR CONTEXTS (round 6).  vtmc_context_stream hands raw hipStream_t handles to the host, and host-side objects keep
+// referring to them after vtmc_destroy -- events recorded on them, a framework's stream wrapper, a caching allocator that records an event on
+// the stream when it frees a pinned buffer that was copied on it: round 5's aborts in the interpreter's tear-down.  A context therefore does
+// not destroy its streams: vtmc_destroy drains them and parks them here, per device and kind, and the next context on that device takes a
+// parked one.  Bounded by the largest number of contexts alive at once; the HIP runtime reclaims them at process exit.  VTMC_STREAM_POOL=0
+// in the environment (test switch) restores destruction in vtmc_destroy.
+namespace {
+struct StreamPool {
+    std::mutex m;
+    std::vector<std::pair<int, hipStream_t>> parked[2];   // [0] ordinary non-blocking streams, [1] streams on a hardware queue of their own
+};
+StreamPool &stream_pool()
+{
+    static StreamPool *p = new StreamPool;   // never destructed: no static destructor that could run beside the HIP runtime's own at exit
+    return *p;
+}
+bool env_is(const char *name, const char *value)
+{
+    const char *v = getenv(name);
+    return v && !strcmp(v, value);
+}
+bool stream_pool_enabled()
+{
+    static const bool on = !env_is("VTMC_STREAM_POOL", "0");
+    return on;
+}
+}  // namespace
+
+// A stream of `device` (current): own_queue = made by hipExtStreamCreateWithCUMask with every CU named -- such a stream always sits on a
+// hardware queue of its own, ordinary streams share a handful (profiles/r05/stream_overlap.txt).
+hipError_t take_stream(int device, bool own_queue, int n_cus, hipStream_t *out)
+{
+    if (stream_pool_enabled()) {
+        StreamPool &sp = stream_pool();
+        std::lock_guard<std::mutex> g(sp.m);
+        auto &v = sp.parked[own_queue ? 1 : 0];
+        for (size_t i = v.size(); i-- > 0;)   // the one parked last
+            if (v[i].first == device) {
+                *out = v[i].second;
+                v.erase(v.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    if (!own_queue) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    std::vector<uint32_t> mask((size_t)(n_cus + 31) / 32, 0xFFFFFFFFu);
+    if (n_cus % 32) mask.back() = (1u << (n_cus % 32)) - 1u;
+    return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+}
+// the stream is idle (the caller synchronised it)
+void park_stream(int device, bool own_queue, hipStream_t s)
+{
+    if (!s) return;
+    if (!stream_pool_enabled()) {
+        quiet(hipStreamDestroy(s));
+        return;
+    }
+    StreamPool &sp = stream_pool();
+    std::lock_guard<std::mutex> g(sp.m);
+    sp.parked[own_queue ? 1 : 0].emplace_back(device, s);
+}
+
 
 int fail(vtmc_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -352,7 +416,10 @@ int32_t vtmc_create(int32_t device, vtmc_ctx **out_ctx)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    // test switch (tests/test_own_queue_cpp_host.py): the context's MAIN stream on a hardware queue of its own, pinned staging and read-backs
+    // included -- the configuration whose C++ host hung at process exit in round 5 ("Streams")
+    ctx->stream_own_queue = env_is("VTMC_TEST_MAIN_STREAM_OWN_QUEUE", "1");
+    if ((e = take_stream(device, ctx->stream_own_queue, ctx->n_cus, &ctx->stream)) != hipSuccess) return bail("hipStreamCreate", e);
     for (auto &ev : ctx->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     for (auto &ev : ctx->ev_fill)
@@ -385,16 +452,21 @@ int32_t vtmc_destroy(vtmc_ctx *ctx)
 {
     if (!ctx) return VTMC_OK;
     quiet(hipSetDevice(ctx->device));
+    // 1. nothing of this context is still running: a queued extract nobody finished (on whatever stream the caller named), the own-queue
+    //    stream, the collective's stream, the ordinary stream -- BEFORE anything they use is released (round 5 freed device and pinned memory
+    //    first and synchronised the own-queue stream last)
+    if (ctx->pending.active && ctx->pending.stream) quiet(hipStreamSynchronize(ctx->pending.stream));
+    if (ctx->queue_stream) quiet(hipStreamSynchronize(ctx->queue_stream));
+    if (ctx->comm_stream) quiet(hipStreamSynchronize(ctx->comm_stream));
     if (ctx->stream) quiet(hipStreamSynchronize(ctx->stream));
-    comm_release(ctx);
-    for (DevBuf *b : {&ctx->d_vert, &ctx->d_trinum, &ctx->counts, &ctx->offsets, &ctx->active, &ctx->partials, &ctx->totals,
-                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->yrows, &ctx->signs, &ctx->terrain, &ctx->heightmap,
-                      &ctx->vcounts, &ctx->voffsets, &ctx->vtotals, &ctx->verts, &ctx->indices, &ctx->chunk_image,
-                      &ctx->comm_send})
-        release(*b);
-    release_pinned((void **)&ctx->h_totals, nullptr);
-    release_pinned((void **)&ctx->h_origins, &ctx->h_origins_bytes);
-    release_pinned((void **)&ctx->h_stage, &ctx->h_stage_bytes);
+    comm_release(ctx);   // drains the collectives queued through the communicator (also on a stream of the caller's), then lets go of it
+    // 2. the streams: parked for the next context of this device, never destroyed -- handles from vtmc_context_stream stay valid for host-side
+    //    objects that outlive the context (see StreamPool above; VTMC_STREAM_POOL=0: destroyed here, ahead of the events and the memory)
+    park_stream(ctx->device, false, ctx->comm_stream);
+    park_stream(ctx->device, true, ctx->queue_stream);
+    park_stream(ctx->device, ctx->stream_own_queue, ctx->stream);
+    ctx->comm_stream = ctx->queue_stream = ctx->stream = nullptr;
+    // 3. events, 4. device buffers and pinned memory
     if (ctx->ev_origins) quiet(hipEventDestroy(ctx->ev_origins));
     for (auto &ev : ctx->ev)
         if (ev) quiet(hipEventDestroy(ev));
@@ -403,12 +475,14 @@ int32_t vtmc_destroy(vtmc_ctx *ctx)
     if (ctx->ev_gather) quiet(hipEventDestroy(ctx->ev_gather));
     if (ctx->ev_last_gather) quiet(hipEventDestroy(ctx->ev_last_gather));
     if (ctx->ev_comm_chain) quiet(hipEventDestroy(ctx->ev_comm_chain));
-    if (ctx->comm_stream) quiet(hipStreamDestroy(ctx->comm_stream));
-    if (ctx->queue_stream) {
-        quiet(hipStreamSynchronize(ctx->queue_stream));
-        quiet(hipStreamDestroy(ctx->queue_stream));
-    }
-    if (ctx->stream) quiet(hipStreamDestroy(ctx->stream));
+    for (DevBuf *b : {&ctx->d_vert, &ctx->d_trinum, &ctx->counts, &ctx->offsets, &ctx->active, &ctx->partials, &ctx->totals,
+                      &ctx->volcounts, &ctx->cases, &ctx->tris, &ctx->input, &ctx->list, &ctx->perm, &ctx->origins, &ctx->yrows, &ctx->signs, &ctx->terrain, &ctx->heightmap,
+                      &ctx->vcounts, &ctx->voffsets, &ctx->vtotals, &ctx->verts, &ctx->indices, &ctx->chunk_image,
+                      &ctx->comm_send})
+        release(*b);
+    release_pinned((void **)&ctx->h_totals, nullptr);
+    release_pinned((void **)&ctx->h_origins, &ctx->h_origins_bytes);
+    release_pinned((void **)&ctx->h_stage, &ctx->h_stage_bytes);
     delete ctx;
     return VTMC_OK;
 }
@@ -767,12 +841,11 @@ int32_t vtmc_context_stream(vtmc_ctx *ctx, int32_t own_queue, void **stream)
     // A stream on a HARDWARE QUEUE OF ITS OWN.  Ordinary HIP streams share a handful of queues, and two contexts whose streams land on one
     // queue run their steps strictly one behind the other; on queues of their own, step k + 1's classify kernel starts on the CUs step k's
     // emit kernel leaves as it drains (profiles/r05/stream_overlap.txt: -4..5 % of a 1024^3 step, -20 % of a rank's step of an 8-rank run).
-    // A stream made with a CU mask always gets its queue; the mask names every CU.  Made on first request, destroyed with the context.
+    // A stream made with a CU mask always gets its queue; the mask names every CU.  Taken on first request (a parked one of an earlier
+    // context, or a new one); parked again, not destroyed, by vtmc_destroy: the handle stays valid until the process exits.
     if (!ctx->queue_stream) {
         VTMC_HIP(ctx, hipSetDevice(ctx->device));
-        std::vector<uint32_t> mask((size_t)(ctx->n_cus + 31) / 32, 0xFFFFFFFFu);
-        if (ctx->n_cus % 32) mask.back() = (1u << (ctx->n_cus % 32)) - 1u;
-        const hipError_t e = hipExtStreamCreateWithCUMask(&ctx->queue_stream, (uint32_t)mask.size(), mask.data());
+        const hipError_t e = take_stream(ctx->device, true, ctx->n_cus, &ctx->queue_stream);
         if (e != hipSuccess) {
             quiet(e);
             ctx->queue_stream = nullptr;

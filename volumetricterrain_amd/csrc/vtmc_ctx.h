@@ -30,6 +30,7 @@ struct vtmc_ctx {
     int device = 0;
     int n_cus = 256;
     hipStream_t stream = nullptr;         // the context's own stream (what `stream` = NULL means in the ABI)
+    bool stream_own_queue = false;        // test switch VTMC_TEST_MAIN_STREAM_OWN_QUEUE=1: `stream` itself sits on a hardware queue of its own
     hipStream_t queue_stream = nullptr;   // vtmc_context_stream(own_queue = 1): a stream on a hardware queue of its own, made on request
     vtmc::DeviceTables tables{nullptr, nullptr};
     VtmcDevBuf d_vert, d_trinum;
@@ -101,6 +102,9 @@ int ensure(vtmc_ctx *ctx, VtmcDevBuf &b, size_t bytes);  // grow-only device buf
 void release(VtmcDevBuf &b);
 const char *create_error_text();
 void comm_release(vtmc_ctx *ctx);  // comm.hip: called by vtmc_destroy
+// vtmc_api.hip: a context's streams come from (and return to) a per-device pool and are never destroyed -- see StreamPool there
+hipError_t take_stream(int device, bool own_queue, int n_cus, hipStream_t *out);
+void park_stream(int device, bool own_queue, hipStream_t s);
 }  // namespace vtmc
 
 #define VTMC_HIP(ctx, expr)                                                                                \

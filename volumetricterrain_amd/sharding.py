@@ -5,6 +5,11 @@ Unit = one chunk of chunk_cells^3 cells with its +2 sample halo (independent: a 
 its own 10^3 samples, VoxelTerrain.cs:346-359).  Chunk c belongs to rank c % world_size.  The only
 exchange is one all-gather of the per-chunk {vertex count, triangle count} pairs, after which every
 rank derives the global offsets with a local exclusive scan.  No density or mesh data crosses GPUs.
+
+Round 6: any partition of the chunks is as good as another for the results (they are independent), but not for the step's
+length -- the surface is not spread evenly, and the step ends when the heaviest rank does.  c % 8 leaves the heaviest rank of
+the benchmark world 3.0 % above the mean; balanced_assignment() cuts the chunks by the counts every rank already holds after
+the first step's all-gather (the same on every rank, so every rank derives the same partition without another exchange).
 """
 import numpy as np
 
@@ -31,6 +36,75 @@ def chunk_origins(n, chunk_cells, rank=0, world_size=1):
 
 def owned_chunks(n_chunks, rank, world_size):
     return list(range(rank, n_chunks, world_size))
+
+
+def origins_of(n, chunk_cells, chunk_ids):
+    """Global sample origins of the named chunks (chunk c = cx + ncx*(cy + ncy*cz)), in the order given."""
+    ncx, ncy, _ = chunk_grid(n, chunk_cells)
+    out = [((c % ncx) * chunk_cells, ((c // ncx) % ncy) * chunk_cells, (c // (ncx * ncy)) * chunk_cells) for c in chunk_ids]
+    return np.asarray(out, np.int32).reshape(-1, 3)
+
+
+def modulo_assignment(n_chunks, world_size):
+    """rank -> its chunk ids under the default rule c % world_size."""
+    return [owned_chunks(n_chunks, r, world_size) for r in range(world_size)]
+
+
+def balanced_assignment(costs, world_size):
+    """rank -> sorted chunk ids, every rank at most ceil(n / world) chunks, the ranks' cost sums as equal as a greedy cut makes
+    them: chunks by falling cost (ties by id) go to the lightest rank that still has room, then pairs of chunks are swapped
+    between the heaviest rank and the others while that lowers the maximum.  Deterministic in `costs` alone: every rank holds the
+    same all-gathered counts and derives the same lists."""
+    costs = [int(c) for c in costs]
+    n = len(costs)
+    cap = (n + world_size - 1) // world_size
+    lists = [[] for _ in range(world_size)]
+    load = [0] * world_size
+    for c in sorted(range(n), key=lambda i: (-costs[i], i)):
+        r = min((r for r in range(world_size) if len(lists[r]) < cap), key=lambda r: (load[r], r))
+        lists[r].append(c)
+        load[r] += costs[c]
+    for _ in range(4 * n):   # refinement: bounded, every accepted swap lowers the pair's maximum
+        hi = max(range(world_size), key=lambda r: (load[r], -r))
+        best = None
+        for lo in range(world_size):
+            if lo == hi:
+                continue
+            gap = load[hi] - load[lo]
+            for a in lists[hi]:
+                for b in lists[lo]:
+                    d = costs[a] - costs[b]          # moves d from hi to lo
+                    if 0 < d < gap and (best is None or abs(gap - 2 * d) < best[0]):
+                        best = (abs(gap - 2 * d), lo, a, b, d)
+        if best is None:
+            break
+        _, lo, a, b, d = best
+        if max(load[hi] - d, load[lo] + d) >= load[hi]:
+            break
+        lists[hi].remove(a)
+        lists[lo].remove(b)
+        lists[hi].append(b)
+        lists[lo].append(a)
+        load[hi] -= d
+        load[lo] += d
+    return [sorted(x) for x in lists]
+
+
+def slot_permutation(assignment, per_rank):
+    """perm[c] = index of chunk c in the gathered (world x per_rank) array: rank r's k-th chunk sits in slot r * per_rank + k."""
+    n = sum(len(a) for a in assignment)
+    perm = np.zeros(n, np.intp)
+    for r, a in enumerate(assignment):
+        for k, c in enumerate(a):
+            perm[c] = r * per_rank + k
+    return perm
+
+
+def imbalance(costs, assignment):
+    """max over ranks / mean over ranks of the summed cost (1.0 = perfectly even)."""
+    sums = [sum(int(costs[c]) for c in a) for a in assignment]
+    mean = sum(sums) / max(len(sums), 1)
+    return (max(sums) / mean) if mean > 0 else 1.0
 
 
 def global_offsets(all_counts):

@@ -37,7 +37,7 @@ class ChunkStream:
                 e.set_tuning(density_wgs_per_cu=int(sampler_wgs_per_cu))
         with torch.cuda.device(device):
             self._buf = [torch.empty(self.batch * self.dim ** 3, dtype=torch.float32, device="cuda") for _ in range(2)]
-            self._stream = torch.cuda.Stream()
+            self._stream = None if two_queues else torch.cuda.Stream()   # rounds 2-4: one torch stream for both contexts
         # two_queues (default): each context's sampler and extract on the context's own-queue stream (a hardware queue each,
         # vtmc_context_stream) instead of one stream for both: S0 E0 S2 E2 ... beside S1 E1 S3 E3 ...; 18.9 against 19.8 ms per 2048^3 pass
         # (profiles/r05/stream2048_two_queues.txt)
