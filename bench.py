@@ -162,6 +162,13 @@ def report(kind, **kw):
             pass
 
 
+def emit_partial(obj, what):
+    """A first / intermediate form of the line, for the supervisor only (it prints the LAST line it received): if anything behind this point
+    fails, what was measured so far is not lost.  --direct prints nothing until the full line."""
+    if _REPORT_FD is not None:
+        emit_line(dict(obj, partial=what))
+
+
 def emit_line(obj):
     """The ONE line of the contract.  Under a supervisor it travels through the pipe (the supervisor prints the LAST one it received, once, when the
     worker has ended -- so the worker may send a first, short form right after the timed region and the full one later); --direct: real stdout."""
@@ -960,7 +967,7 @@ def run_grid(args, torch, dist, wd):
             out["fallback_reason"] = os.environ.get("VTMC_BENCH_FALLBACK_REASON", "")
         report("done")
         if rank == 0:   # a first, short form of the line: if anything behind the timed region fails, the measurement itself is not lost
-            emit_line(dict(out, partial="everything behind the timed region (kernel rooflines, indexed output, CPU leg, rehearsal) is missing: the worker ended before it sent the full line"))
+            emit_partial(out, "everything behind the timed region (kernel rooflines, indexed output, CPU leg, rehearsal) is missing: the worker ended before it sent the full line")
 
         # The kernels' own durations.  With a stream per context the HIP events around a kernel also see the time it waits for CUs beside the
         # other context's kernels (a classify kernel "takes" 1.9 ms there): the roofline of a KERNEL needs it alone on the chip.  A second
@@ -1038,7 +1045,7 @@ def run_grid(args, torch, dist, wd):
                 "sampler_s": round(sampler_s, 4),
                 "sampler_kernel_ms": round(sampler_kernel_ms, 3),
             })
-            emit_line(dict(out, partial="indexed output, CPU leg, rehearsal and stream record are missing: the worker ended before it sent the full line"))
+            emit_partial(out, "indexed output, CPU leg, rehearsal and stream record are missing: the worker ended before it sent the full line")
 
             # the same workload in the welded (indexed) output format -- 24 B per vertex + 12 B per triangle instead of 76 B
             # per triangle: a few steps after the timed region, N = 1 only (not part of `value`)
@@ -1134,7 +1141,7 @@ def run_grid(args, torch, dist, wd):
     if rank == 0:
         if world == 1 and not args.no_stream_record and c == 128 and (n == 1024 or args.stream_record_cells != 2048):
             wd.stage("stream_record", 240)
-            emit_line(dict(out, partial="the stream2048 sub-record is missing: the worker ended before it sent the full line"))
+            emit_partial(out, "the stream2048 sub-record is missing: the worker ended before it sent the full line")
             try:
                 out["stream2048"] = stream_sub_record(torch, args, local)
             except Exception as e:   # noqa: BLE001
@@ -1235,7 +1242,7 @@ def run_stream(args, torch, dist, wd):
         }
         if fallback:
             out["fallback_reason"] = os.environ.get("VTMC_BENCH_FALLBACK_REASON", "")
-        emit_line(dict(out, partial="the CPU leg is missing: the worker ended before it sent the full line"))
+        emit_partial(out, "the CPU leg is missing: the worker ended before it sent the full line")
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             wd.stage("cpu_baseline", 300)

@@ -70,6 +70,35 @@ __global__ __launch_bounds__(256) void mix_kernel(const v4f *__restrict__ src, v
     }
 }
 
+// The same R : W mix with ONE read front and ONE write front per workgroup: unit u of a workgroup's step reads the R consecutive 4-KiB pieces
+// (u R + r) of `src` and writes the W consecutive pieces (u W + w) of `dst` -- two address streams instead of mix_kernel's R + W.
+template <int R, int W, int U>
+__global__ __launch_bounds__(256) void mix_contig_kernel(const v4f *__restrict__ src, v4f *__restrict__ dst, long long n_units)
+{
+    for (long long u0 = (long long)blockIdx.x * U; u0 < n_units; u0 += (long long)gridDim.x * U) {
+        v4f acc[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+            if (u0 + j < n_units) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[j] += src[((u0 + j) * R + r) * 256 + threadIdx.x];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            if (u0 + j < n_units) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    v4f v = acc[j];
+                    v.x += (float)w;
+                    dst[((u0 + j) * W + w) * 256 + threadIdx.x] = v;
+                }
+            }
+        }
+    }
+}
+
 // The emit kernel's own traffic shape without its arithmetic: a wave gathers `rows` 40-byte rows (10 lanes each, 5 rows per load
 // instruction, rows at a 520-byte pitch like a 130-sample grid line) and writes `tris` 76-byte records as one contiguous stream of
 // float4 (the staged form).  rows / tris per wave-step = 64 / 128: a tile after row masks and an average block's triangles.
@@ -380,6 +409,12 @@ int main(int argc, char **argv)
         mx = std::max(mx, 11.0 * u * 16.0 / median_ms([&] { hipLaunchKernelGGL((mix_kernel<4, 7, 4, false>), dim3(4 * n_cus), dim3(256), 0, 0, buf, buf + 4 * u, u); }) / 1e9);
         mx = std::max(mx, 11.0 * u * 16.0 / median_ms([&] { hipLaunchKernelGGL((mix_kernel<4, 7, 4, false>), dim3(2 * n_cus), dim3(256), 0, 0, buf, buf + 4 * u, u); }) / 1e9);
         mx = std::max(mx, 11.0 * u * 16.0 / median_ms([&] { hipLaunchKernelGGL((mix_kernel<4, 7, 8, false>), dim3(2 * n_cus), dim3(256), 0, 0, buf, buf + 4 * u, u); }) / 1e9);
+        {   // one read front + one write front per workgroup: units of 4 + 7 pieces of 4 KiB
+            const long long nu = n / (11 * 256);
+            mx = std::max(mx, 11.0 * nu * 4096.0 / median_ms([&] { hipLaunchKernelGGL((mix_contig_kernel<4, 7, 1>), dim3(8 * n_cus), dim3(256), 0, 0, buf, buf + 4 * nu * 256, nu); }) / 1e9);
+            mx = std::max(mx, 11.0 * nu * 4096.0 / median_ms([&] { hipLaunchKernelGGL((mix_contig_kernel<4, 7, 2>), dim3(4 * n_cus), dim3(256), 0, 0, buf, buf + 4 * nu * 256, nu); }) / 1e9);
+            mx = std::max(mx, 11.0 * nu * 4096.0 / median_ms([&] { hipLaunchKernelGGL((mix_contig_kernel<4, 7, 1>), dim3((unsigned)nu), dim3(256), 0, 0, buf, buf + 4 * nu * 256, nu); }) / 1e9);
+        }
         // the emit kernel's own access shape (40-byte rows gathered, 76-byte records streamed), without its arithmetic
         const long long dst_f4 = n * 3 / 4, src_floats = (n - dst_f4) * 4, n_steps = dst_f4 / 608;
         const float *src = reinterpret_cast<const float *>(buf + dst_f4);
@@ -387,7 +422,7 @@ int main(int argc, char **argv)
         for (int per_cu : {4, 8})
             es = std::max(es, (double)n_steps * (608.0 * 16 + 64 * 40) / median_ms([&] { hipLaunchKernelGGL(emit_shape_kernel, dim3(per_cu * n_cus), dim3(256), 0, 0, src, src_floats, buf, n_steps); }) / 1e9);
         printf("{\"kernel\": \"box\", \"GiB\": %.2f, \"read_TBps\": %.3f, \"write_TBps\": %.3f, \"copy_TBps\": %.3f, \"mix_4r7w_TBps\": %.3f, \"emit_shape_TBps\": %.3f, "
-               "\"cus\": %d, \"device\": \"%s\"}\n", gib, rd, wr, cp, mx, es, n_cus, prop.name);
+               "\"cus\": %d, \"device\": \"%s\"}\n", gib, rd, wr, cp, mx, es, n_cus, prop.gcnArchName);
         fflush(stdout);
         CK(hipFree(buf));
         return 0;

@@ -24,6 +24,8 @@ d = torch.empty(len(org) * dim ** 3, dtype=torch.float32, device="cuda")
 ex.density_fill_device(vt.density_params("perlin3d", n), org, (dim, dim, dim), (1, dim, dim * dim), dim ** 3, d.data_ptr())
 for spec in sys.argv[1:] or ["base"]:
     kv = {} if spec == "base" else {k: int(v) for k, v in (it.split("=") for it in spec.split(","))}
+    indexed = bool(kv.pop("indexed", 0))   # indexed=1: the welded output's kernel (phases 3-6: numbering | vertices | slots | index triples)
+    ex.set_output_mode(indexed)
     ex.set_tuning(emit_ablate=0)
     ex.set_tuning(**kv)
     for _ in range(3):
@@ -40,5 +42,6 @@ for spec in sys.argv[1:] or ["base"]:
     t = buf.cpu().numpy()
     tot, blocks = float(t[:8].sum()), int(t[8]) // K
     print("== %s: emit %.3f ms (instrumented), %d blocks per launch, %.0f cycles per block and wave" % (spec, ms, blocks, tot / max(t[8], 1)))
+    names = NAMES if not indexed else NAMES[:3] + ["N: vertex numbering", "V: vertex evaluation + vertex stores", "pass 2: triangle slots", "T: index triples + stores", NAMES[7]]
     for i in range(8):
-        print("   %-52s %5.1f %%   %7.0f cycles per block" % (NAMES[i], 100.0 * t[i] / tot, t[i] / max(t[8], 1)))
+        print("   %-52s %5.1f %%   %7.0f cycles per block" % (names[i], 100.0 * t[i] / tot, t[i] / max(t[8], 1)))

@@ -728,7 +728,7 @@ template <bool FAST>
 __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_vert, const unsigned short *s_own, const IdxTables *tb,
                                                    size_t tri_base, int tri_budget, size_t vert_base, int vert_budget,
                                                    float *__restrict__ out_vertices, int *__restrict__ out_indices, int lane, int ablate,
-                                                   unsigned rowmask, int &vm_issued)
+                                                   unsigned rowmask, int &vm_issued, PhaseClock &pc)
 {
     typedef float v3u __attribute__((ext_vector_type(3), aligned(4)));
     typedef int i3u __attribute__((ext_vector_type(3), aligned(4)));
@@ -736,6 +736,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
     // pass 1: compaction of the active cells (as the soup path, row masks included)
     const int n_act = compact_active_cells(tile, L->acell, L->cases, lane, rowmask);
     VTMC_WAVE_SYNC();
+    pc.mark(2);
     const bool big = vert_budget > kIdxFastVerts;   // wave-uniform: the scan's vertex count of this block decides the numbering's form
 
     // N: vertex numbering over the active cells, 64 per step.  Descriptors of the ids in [window, window + kVlistCap) are queued.
@@ -778,6 +779,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
     };
     int n_vert = number_cells(0, true);
     if (n_vert > vert_budget) n_vert = vert_budget;  // never outside the block's slice of the vertex buffer
+    pc.mark(3);
 
     // V: one lane per vertex, from the edge's low endpoint; position and normal leave as two 12-byte stores per lane
     for (int window = 0; window < n_vert; window += kVlistCap) {
@@ -799,6 +801,7 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
         }
         VTMC_WAVE_SYNC();
     }
+    pc.mark(4);
 
     // pass 2 + T: triangle slots, 64 active cells per step; a triangle lane finds each of its three vertices in the lattice-edge table
     // (or, in a block of more than 255 vertices, through its edge's owner cell) and writes its index triple from registers
@@ -853,7 +856,9 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
         pending += (int)step_total;
     }
     if (pending > tri_budget) pending = tri_budget;
+    pc.mark(5);
     if (pending > 0) flush(pending, tri_base);
+    pc.mark(6);
 }
 
 }  // namespace vtmc

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg, ONCE ? 3 : 4) void emit_kernel(Bl
             const int budget = (int)cur.tri_cnt;
             if constexpr (INDEXED)
                 emit_block_indexed<FAST>(L, s_vert, s_own, &s_once[0], (size_t)cur.tri_base, budget, (size_t)cur.vert_base, (int)cur.vert_cnt, out,
-                                         out_indices, lane, ablate, cur.mask, vm_issued);
+                                         out_indices, lane, ablate, cur.mask, vm_issued, pc);
             else if constexpr (ONCE)
                 emit_block_once<FAST>(L, s_vert, &s_once[0], (size_t)cur.tri_base, budget, cur.b, out, lane, ablate, cur.mask, vm_issued, pc);
             else
