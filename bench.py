@@ -100,7 +100,7 @@ def parse(argv=None):
                     help="grid1024: steps in flight = contexts taking turns (each with its own result buffers); step k + d - 1 is queued before the "
                          "host takes step k's result -- the device never waits for the host.  Default 4 (rounds 2-5a: 2): in ONE process, "
                          "alternating, 4 in flight run a rank's step of an 8-rank run 8 %% faster than 2 (0.2154 against 0.2341 ms with the collective "
-                         "and the host's read-back in the loop) and the whole 1024^3 step 1-2 %% (tools/depth_probe.py, profiles/r05/depth_probe.txt).  "
+                         "and the host's read-back in the loop) and the whole 1024^3 step 1-2 %% (profiles/r05/depth_probe.txt).  "
                          "At N > 1 all contexts issue their all-gather through ONE communicator (vtmc_comm_share).  1: every step ends with its host "
                          "wait (the latency of an isolated step, also reported as step_latency_ms)")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
@@ -887,7 +887,7 @@ def run_grid(args, torch, dist, wd):
         if force_comm:
             pipe.world_of_one_comm()
         exchange = world > 1 or force_comm
-        # N > 1: a rank's kernels take 0.14 ms each, and the HIP events between them cost 2 % of its step (tools/rank_step.py): only every eighth
+        # N > 1: a rank's kernels take 0.14 ms each, and the HIP events between them cost 2 % of its step (DESIGN_HISTORY.md, round 3): only every eighth
         # step carries them (the same steps whose collective is timed); at N = 1 every step does (0.3 % of a step)
         sample_stages = world > 1
         kw = {"backend": backend, "dist": dist, "sharding": sharding}

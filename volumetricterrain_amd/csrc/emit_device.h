@@ -681,14 +681,15 @@ struct __attribute__((aligned(16))) EmitLdsIdx {
         unsigned slot[kSlotCap];          // pass 2: triangle slot -> cell | edge triple << 9.  Over the tile: nothing reads a sample after the vertex
                                           // phase (pass 2 takes the cases from `cases`), and the next tile is stored at the top of the next block
     } t;
-    unsigned short vlist[kVlistCap];  // vertex phase: vertex id - window -> low lattice point (x | y << 4 | z << 8) | axis << 12
+    unsigned short vlist[kVlistCap + 8];  // vertex phase: vertex id - window -> low lattice point (x | y << 4 | z << 8) | axis << 12; entry kVlistCap: the
+                                          // dump of lanes that own nothing in a numbering round (branch-free rounds, round 6)
     unsigned short acell[512];      // active cells of the block, ascending cell id
     union {
         unsigned char vtab[2192];   // <= 255 vertices: lattice edge (axis * 729 + x + 9 y + 81 z) -> vertex id
         unsigned cellmap[512];      // more: owner cell -> first vertex id | owned-edge mask << 16 (active cells only)
     } m;
     unsigned char cases[512];       // cases[i]: the case of cell acell[i] (pass 1 -> numbering -> pass 2)
-};   // 8240 bytes: with the shared tables a workgroup of THREE waves takes 27 024 bytes -- six per CU, 18 waves (four-wave workgroups: 16)
+};   // 8256 bytes: with the shared tables a workgroup of four waves takes 35.3 KB -- four per CU, 16 waves
 static_assert(sizeof(EmitLdsIdx) % 16 == 0, "keeps the waves' blocks 16-byte aligned");
 
 
@@ -740,7 +741,51 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
     const bool big = vert_budget > kIdxFastVerts;   // wave-uniform: the scan's vertex count of this block decides the numbering's form
 
     // N: vertex numbering over the active cells, 64 per step.  Descriptors of the ids in [window, window + kVlistCap) are queued.
-    auto number_cells = [&](int window, bool first) {
+    // The kernel is bound by ISSUED instructions and a scalar one costs what a vector one does (profiles/r05/emit_issue_bound.txt;
+    // profiles/r06/sq_counters_indexed.txt: 412 scalar + 114 branch instructions per block beside 643 vector ones), so (round 6) the two forms
+    // of the numbering are two loops -- no wave-uniform `big` test inside the rounds -- and the three rounds every step runs (the edges at a
+    // cell's corner 0) are branch-free: a lane that owns nothing writes the lists' dump entries instead of sitting out an exec region.
+    auto number_small = [&]() {   // at most kIdxFastVerts vertices: one window, every id has its byte in vtab
+        int vrun = 0;
+        for (int c0 = 0; c0 < n_act; c0 += 64) {
+            const int idx = c0 + lane;
+            const bool valid = idx < n_act;
+            const int ic = valid ? idx : n_act - 1;
+            const unsigned cell = L->acell[ic];
+            const unsigned cs = valid ? (unsigned)L->cases[ic] : 0u;   // case 0: no edges
+            const unsigned cx = cell & 7u, cy = (cell >> 3) & 7u, cz = cell >> 6;
+            const unsigned b7 = (unsigned)(cx == 7u) | ((unsigned)(cy == 7u) << 1) | ((unsigned)(cz == 7u) << 2);
+            const unsigned owned = case_edge_mask(cs) & (0x109u | tb->ownx[b7]);
+            const unsigned desc = cx | (cy << 4) | (cz << 8);
+            const unsigned cell9 = cx + 9u * cy + 81u * cz;
+            unsigned step_total;
+            const unsigned id0 = (unsigned)vrun + wave_prefix4((unsigned)__builtin_popcount(owned), step_total);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {   // cube edges 0, 3, 8: no branch, no exec region
+                const unsigned e = kOwnedEdgeOrder[r], ed = once_edge_entry(kOwnedEdgeOrder[r]);
+                const bool has = ((owned >> e) & 1u) != 0u;
+                const unsigned id = id0 + (unsigned)__builtin_popcount(owned & ((1u << e) - 1u));
+                L->vlist[has ? (id & 255u) : (unsigned)kVlistCap] = (unsigned short)(desc + (ed & 0xFFFFu));   // & 255: a count mismatch could never write outside the list
+                L->m.vtab[has ? cell9 + (ed >> 16) : 2191u] = (unsigned char)id;                                 // 2187 lattice edges: bytes 2187-2191 are spare
+            }
+            if (__builtin_amdgcn_ballot_w64((owned & 0xEF6u) != 0u) != 0ull) {   // wave-uniform: some cell of the step owns an edge of a far face
+#pragma unroll
+                for (int r = 3; r < 12; ++r) {
+                    const unsigned e = kOwnedEdgeOrder[r], ed = once_edge_entry(kOwnedEdgeOrder[r]);
+                    const bool has = ((owned >> e) & 1u) != 0u;
+                    if (__builtin_amdgcn_ballot_w64(has) == 0ull) continue;   // wave-uniform
+                    if (has) {
+                        const unsigned id = id0 + (unsigned)__builtin_popcount(owned & ((1u << e) - 1u));
+                        L->vlist[id & 255u] = (unsigned short)(desc + (ed & 0xFFFFu));
+                        L->m.vtab[cell9 + (ed >> 16)] = (unsigned char)id;
+                    }
+                }
+            }
+            vrun += (int)step_total;
+        }
+        return vrun;
+    };
+    auto number_big = [&](int window, bool first) {   // more: the owner-cell map of round 2, descriptors window by window
         int vrun = 0;
         for (int c0 = 0; c0 < n_act; c0 += 64) {
             const int idx = c0 + lane;
@@ -751,39 +796,30 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
             const unsigned b7 = (unsigned)(cx == 7u) | ((unsigned)(cy == 7u) << 1) | ((unsigned)(cz == 7u) << 2);
             const unsigned owned = valid ? (case_edge_mask(cs) & (0x109u | tb->ownx[b7])) : 0u;
             const unsigned desc = cx | (cy << 4) | (cz << 8);
-            const unsigned cell9 = cx + 9u * cy + 81u * cz;
             unsigned step_total;
             const int id0 = vrun + (int)wave_prefix4((unsigned)__builtin_popcount(owned), step_total);
-            if (big && first && valid) L->m.cellmap[cell] = (unsigned)id0 | (owned << 16);
-            // one round per cube edge a cell can own (the three at its corner 0, then the far-face edges of a boundary cell): the edge's
-            // geometry is a compile-time constant, its rank among the cell's owned edges a popcount; a round nobody needs is skipped
+            if (first && valid) L->m.cellmap[cell] = (unsigned)id0 | (owned << 16);
 #pragma unroll
             for (int r = 0; r < 12; ++r) {
                 const unsigned e = kOwnedEdgeOrder[r], ed = once_edge_entry(kOwnedEdgeOrder[r]);
                 const bool has = ((owned >> e) & 1u) != 0u;
                 if (r >= 3 && __builtin_amdgcn_ballot_w64(has) == 0ull) continue;   // wave-uniform
                 if (has) {
-                    const int id = id0 + __builtin_popcount(owned & ((1u << e) - 1u));
-                    if (!big) {   // at most 255 vertices: one window, every id has its byte
-                        L->vlist[id & 255] = (unsigned short)(desc + (ed & 0xFFFFu));   // & 255: a count mismatch could never write outside the list
-                        L->m.vtab[cell9 + (ed >> 16)] = (unsigned char)id;
-                    } else {
-                        const int q = id - window;
-                        if (q >= 0 && q < kVlistCap) L->vlist[q] = (unsigned short)(desc + (ed & 0xFFFFu));
-                    }
+                    const int q = id0 + __builtin_popcount(owned & ((1u << e) - 1u)) - window;
+                    if (q >= 0 && q < kVlistCap) L->vlist[q] = (unsigned short)(desc + (ed & 0xFFFFu));
                 }
             }
             vrun += (int)step_total;
         }
         return vrun;
     };
-    int n_vert = number_cells(0, true);
+    int n_vert = big ? number_big(0, true) : number_small();
     if (n_vert > vert_budget) n_vert = vert_budget;  // never outside the block's slice of the vertex buffer
     pc.mark(3);
 
     // V: one lane per vertex, from the edge's low endpoint; position and normal leave as two 12-byte stores per lane
     for (int window = 0; window < n_vert; window += kVlistCap) {
-        if (window > 0) number_cells(window, false);
+        if (window > 0) number_big(window, false);
         VTMC_WAVE_SYNC();
         const int n_w = n_vert - window < kVlistCap ? n_vert - window : kVlistCap;
         for (int s0 = 0; s0 < n_w && !(ablate & 16); s0 += 64) {
@@ -849,10 +885,10 @@ __device__ __forceinline__ void emit_block_indexed(EmitLdsIdx *L, const u64 *s_v
         const unsigned n = (unsigned)(vw >> 60);
         unsigned step_total;
         const unsigned pre_n = wave_prefix3(n, step_total);
-        unsigned *dst = L->t.slot + pending + pre_n;
+        const unsigned d0 = (unsigned)pending + pre_n;
 #pragma unroll
-        for (unsigned i = 0; i < 5; ++i)
-            if (i < n) dst[i] = cell | (((unsigned)(vw >> (12 * i)) & 0xFFFu) << 9);
+        for (unsigned i = 0; i < 5; ++i)   // no exec region per slot: a triangle the cell does not have lands in the dump word behind the slots
+            L->t.slot[i < n ? d0 + i : (unsigned)kSlotCap] = cell | (((unsigned)(vw >> (12 * i)) & 0xFFFu) << 9);
         pending += (int)step_total;
     }
     if (pending > tri_budget) pending = tri_budget;
