@@ -145,7 +145,19 @@ __global__ __launch_bounds__(256) void chunk_write_kernel(v4f *__restrict__ dst,
     } else {
         const long long wave = (long long)blockIdx.x * 4 + w, n_waves = (long long)gridDim.x * 4;
         float a = (float)lane;
-        for (long long c = wave; c < n_chunks; c += n_waves) {
+        // MODE 3: the chunks in a scattered order (c -> c * odd mod 2^k over the largest power of two below n_chunks): every wave's next
+        // chunk is far from its last and from its neighbours'.  MODE 4: `spin` sweep windows (the emit kernel's: 16), each an equal part of
+        // the buffer, swept front to back by the waves w % windows == its index.
+        long long pow2 = 1;
+        while (pow2 * 2 <= n_chunks) pow2 *= 2;
+        for (long long c0 = wave; c0 < (MODE == 3 ? pow2 : n_chunks); c0 += n_waves) {
+            long long c = c0;
+            if (MODE == 3) c = (c0 * 2654435761ll) & (pow2 - 1);
+            if (MODE == 4) {
+                const long long win = c0 % spin, k = c0 / spin, per = n_chunks / spin;
+                if (k >= per) continue;
+                c = win * per + k;
+            }
             v4f *o = dst + c * chunk_f4;
             for (int i = lane; i < chunk_f4; i += 64) {
                 if (MODE == 2) {
@@ -175,7 +187,13 @@ static void run_chunks(const char *name, int wgs_per_cu, int n_cus, v4f *dst, lo
         if (i) CK(hipEventElapsedTime(&ms[i - 1], e0, e1));
     }
     std::sort(ms.begin(), ms.end());
-    const double bytes = (double)n_chunks * chunk_f4 * 16.0;
+    long long written = n_chunks;
+    if (MODE == 3) {   // the scattered order covers the largest power of two of chunks
+        written = 1;
+        while (written * 2 <= n_chunks) written *= 2;
+    }
+    if (MODE == 4) written = (n_chunks / spin) * spin;
+    const double bytes = (double)written * chunk_f4 * 16.0;
     printf("{\"kernel\": \"%s\", \"mode\": %d, \"chunk_bytes\": %d, \"spin\": %d, \"wgs_per_cu\": %d, \"GB\": %.3f, \"ms_med\": %.4f, \"TBps_med\": %.3f, "
            "\"TBps_best\": %.3f}\n", name, MODE, chunk_f4 * 16, spin, wgs_per_cu, bytes / 1e9, ms[reps / 2], bytes / ms[reps / 2] / 1e9, bytes / ms[0] / 1e9);
     fflush(stdout);
@@ -372,7 +390,10 @@ int main(int argc, char **argv)
     const int n_cus = prop.multiProcessorCount;
     const long long total_f4 = (long long)(gib * (1ll << 30)) / 16;
     v4f *buf;
-    CK(hipMalloc(&buf, total_f4 * 16));
+    if (getenv("MIX2_CONTIGUOUS"))   // round 6, profiles/r06/placement_probe.txt: physically contiguous memory instead of hipMalloc's fragments
+        CK(hipExtMallocWithFlags((void **)&buf, total_f4 * 16, hipDeviceMallocContiguous));
+    else
+        CK(hipMalloc(&buf, total_f4 * 16));
     CK(hipMemset(buf, 0, total_f4 * 16));
     const int reps = 7;
 
@@ -534,6 +555,8 @@ int main(int argc, char **argv)
             for (int chunk : {152, 304, 608, 1216, 2432, 9728}) run_chunks<0>("chunk_write", per_cu, n_cus, buf, f4, chunk, 0, reps);
             for (int chunk : {608, 2432}) run_chunks<1>("chunk_write_wg", per_cu, n_cus, buf, f4, chunk, 0, reps);
             for (int spin : {100, 400, 1600}) run_chunks<2>("chunk_write_trickle", per_cu, n_cus, buf, f4, 608, spin, reps);
+            run_chunks<3>("chunk_write_scattered", per_cu, n_cus, buf, f4, 608, 0, reps);
+            for (int windows : {8, 16, 128}) run_chunks<4>("chunk_write_windows", per_cu, n_cus, buf, f4, 608, windows, reps);
         }
         CK(hipFree(buf));
         return 0;
