@@ -20,6 +20,7 @@ ap.add_argument("--rounds", type=int, default=9)
 ap.add_argument("--field-first", action="store_true", help="allocate the density field before the contexts exist")
 ap.add_argument("--tune", default="", help="key=value,... for every context")
 ap.add_argument("--no-realloc", action="store_true")
+ap.add_argument("--lib", default=None, help="another build of the library (path)")
 a = ap.parse_args()
 n, c, dim = 1024, 128, 130
 org = sharding.chunk_origins(n, c)
@@ -30,7 +31,7 @@ def field():
 
 
 d = field() if a.field_first else None
-exs = [vt.Extractor(0) for _ in range(a.contexts)]
+exs = [vt.Extractor(0, lib_path=a.lib) for _ in range(a.contexts)]
 if a.tune:
     for e in exs:
         e.set_tuning(**{k: int(v) for k, v in (it.split("=") for it in a.tune.split(","))})
