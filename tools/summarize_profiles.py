@@ -78,7 +78,8 @@ def main():
         shutil.copy(s1, os.path.join(dst, "kernel_stats_one_stream.csv"))
         shutil.copy(os.path.join(src, "stats_s1", "bench.json"), os.path.join(dst, "bench_under_rocprof_one_stream.json"))
     for name in ("bench_n1.json", "bench_stream2048.json", "bench_2rank_one_device_gloo.json", "bench_world_of_one_comm.json", "rank_step.txt", "rank_step_comm.txt",
-                 "rank_overlap_probe.txt", "rank_overlap_probe_w1.txt", "ab_three_libs.txt", "sq_counters_soup.txt"):
+                 "rank_overlap_probe.txt", "rank_overlap_probe_w1.txt", "ab_three_libs.txt", "sq_counters_soup.txt", "rank_rehearsal_all.txt",
+                 "rank_rehearsal_all_gather_stream_main.txt", "placement_probe_refresh.txt", "ab_r05_r06.txt", "ab_r06_r05.txt"):
         f = os.path.join(src, name)
         if os.path.exists(f) and os.path.getsize(f):
             if name.endswith(".json"):   # torchrun's ranks also print connection chatter on stdout: keep the JSON line
