@@ -182,6 +182,18 @@ def emit_line(obj):
         sys.stdout.flush()
 
 
+def test_hang(wd, stage):
+    """Test hook (tests/test_bench_modes.py): VTMC_BENCH_TEST_HANG="<stage>:<seconds>" makes the FIRST attempt's worker stop answering in that stage
+    with the stage's bound cut to <seconds> -- a real worker, on the GPU, whose watchdog fires and whose supervisor starts the real fallback."""
+    spec = os.environ.get("VTMC_BENCH_TEST_HANG")
+    if not spec or os.environ.get("VTMC_BENCH_FALLBACK") == "1":
+        return
+    name, _, secs = spec.partition(":")
+    if name == stage:
+        wd.stage(stage, float(secs or 3) / wd.scale)
+        time.sleep(1e6)
+
+
 class Refusal(Exception):
     """The run cannot happen at all here (no GPU, a launcher's world of another size): exit code 4, and no second attempt."""
 
@@ -894,6 +906,7 @@ def run_grid(args, torch, dist, wd):
         pipe.bind(d_field.data_ptr(), n_chunks, c, world, per_rank, sharding.slot_permutation(assignment, per_rank), exchange, sample_stages)
 
         wd.stage("warmup", 240)
+        test_hang(wd, "warmup")
         n_warm = max(args.warmup, depth)   # every context once at least: output buffers grow to their size, RCCL builds its channels
         T, offs = pipe.run_steps(depth, False, **kw)
         balance = None
@@ -1344,6 +1357,20 @@ def add_box(out):
 # ------------------------------------------------------------------------------------------------
 # processes: supervisor -> worker (-> one conservative second attempt)
 # ------------------------------------------------------------------------------------------------
+def release_library_streams():
+    """Every context of this process is closed and nothing of torch's refers to their streams any more (run_grid / ChunkStream release in a
+    `finally`): the library's parked streams are destroyed now.  Without it a worker that is profiled (rocprofv3 -- python3 bench.py --direct)
+    ends with own-queue streams alive and crashes in the profiler's finalisation, profile lost."""
+    try:
+        import gc
+        gc.collect()
+        vt = sys.modules.get("volumetricterrain_amd")
+        if vt is not None:
+            vt.release_streams()
+    except Exception as e:   # noqa: BLE001
+        print("bench.py: vtmc_release_streams failed: %s" % e, file=sys.stderr)
+
+
 def worker_main(args):
     """The measuring process.  Under a supervisor: VTMC_BENCH_REPORT_FD names the pipe.  --direct: the line goes to the real stdout."""
     global _REPORT_FD, _REAL_STDOUT
@@ -1375,6 +1402,8 @@ def worker_main(args):
         print(str(e), file=sys.stderr)
         wd.disarm()
         return 4
+    finally:
+        release_library_streams()
     wd.disarm()
     return 0
 

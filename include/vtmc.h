@@ -155,6 +155,13 @@ int32_t vtmc_extract_finish(vtmc_ctx *ctx, int64_t *tri_count);
  * VoxelTerrain.cs:365-427.) */
 int32_t vtmc_context_stream(vtmc_ctx *ctx, int32_t own_queue, void **stream);
 
+/* Destroys the streams the library holds for contexts that no longer exist (the parked ones; a live context keeps its own).  Optional: a host
+ * calls it at a point where nothing of its own refers to a handle of a destroyed context any more -- typically once, before it exits.  Needed
+ * in one situation only: under a profiler (rocprofv3) a process that ends with streams on hardware queues of their own still alive crashes in
+ * the profiler's finalisation and loses the profile; bench.py and the tools that are run under rocprofv3 call it for that reason.  Returns the
+ * number of streams destroyed. */
+int32_t vtmc_release_streams(void);
+
 /* Device pointers to the results of the last extract_* (valid until the next extract_* / destroy):
  * triangles (T x 76 B), block_tri_offsets (n_blocks+1 x u32), volume_counts (n_volumes x
  * {vertices, triangles} u32 -- the array SURVEY.md 8e all-gathers).  Any out pointer may be NULL. */

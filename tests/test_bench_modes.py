@@ -138,3 +138,19 @@ def test_direct_mode_measures_in_one_process():
     """--direct (profilers put the program itself behind `--`): no supervisor, the worker prints the line itself; the watchdog still applies."""
     j = run([sys.executable, "bench.py", "--direct", "--grid", "256", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record"])
     assert j["n_gpus"] == 1 and j["value"] > 0 and "worker" not in j and "error" not in j["box"]
+
+
+def test_a_worker_that_hangs_on_the_gpu_is_replaced_by_the_conservative_one():
+    """The real thing on the GPU box: the first worker stops answering in its warm-up (contexts created, field generated, kernels queued), its
+    watchdog ends it, and the supervisor -- which never touched the GPU -- starts the fallback worker, whose line is a real measurement with
+    the conservative configuration, labelled."""
+    e = dict(os.environ, VTMC_BENCH_TEST_HANG="warmup:4")
+    p = subprocess.run([sys.executable, "bench.py", "--grid", "256", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal",
+                        "--no-stream-record", "--no-box"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = lines[0]
+    assert j["fallback"] is True and "watchdog in stage 'warmup'" in j["fallback_reason"] and j["worker"]["attempts"] == 2
+    assert j["pipeline_depth"] == 2 and j["stream_count"] == 1 and j["value"] > 0 and abs(j["triangles_total"] - 2655156) < 2000
+    assert "WATCHDOG: stage 'warmup'" in p.stderr

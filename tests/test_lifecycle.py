@@ -240,3 +240,9 @@ def test_torch_objects_on_a_contexts_stream_may_outlive_the_context(oracle_mod):
         assert ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 1, dim ** 3, ex.stream_handle(own_queue=True)) == want
     finally:
         ex.close()
+    # vtmc_release_streams: the host says nothing of its own refers to the parked handles any more (a profiled process must, before it exits)
+    torch.cuda.synchronize()
+    assert vt.release_streams() >= 2          # at least this test's own-queue stream and an ordinary one
+    assert vt.release_streams() == 0
+    with vt.Extractor(0) as ex2:              # the next context simply makes new streams
+        assert ex2.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 1, dim ** 3, ex2.stream_handle(own_queue=True)) == want

@@ -67,6 +67,8 @@ def main():
     print("T =", T)
     for v in args.variants:
         print("%-48s" % v, "  ".join("%s med %.4f min %.4f" % (k, statistics.median(x), min(x)) for k, x in res[v].items()))
+    ex.close()
+    vt.release_streams()   # this tool runs under rocprofv3: no stream of the library's may be alive when the profiler finalises
 
 
 if __name__ == "__main__":

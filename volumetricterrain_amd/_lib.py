@@ -36,7 +36,7 @@ SYMBOLS = [
     "vtmc_set_output_mode", "vtmc_last_vertex_count", "vtmc_read_indexed_mesh", "vtmc_device_indexed_results",
     "vtmc_comm_unique_id", "vtmc_comm_init_rank", "vtmc_comm_destroy", "vtmc_comm_share", "vtmc_allgather_volume_counts",
     "vtmc_copy_to_host", "vtmc_chunk_write", "vtmc_chunk_read",
-    "vtmc_extract_volumes_device_async", "vtmc_extract_finish", "vtmc_last_fill_ms", "vtmc_context_stream",
+    "vtmc_extract_volumes_device_async", "vtmc_extract_finish", "vtmc_last_fill_ms", "vtmc_context_stream", "vtmc_release_streams",
 ]
 COMM_ID_BYTES = 128
 
@@ -119,6 +119,8 @@ def load(path=None):
     L.vtmc_last_fill_ms.argtypes = [vp, P(ctypes.c_float)]
     if not explicit or hasattr(L, "vtmc_context_stream"):   # an older build loaded beside the product's (A/B tools) may lack the newest entry points
         L.vtmc_context_stream.argtypes = [vp, i32, P(vp)]
+    if not explicit or hasattr(L, "vtmc_release_streams"):
+        L.vtmc_release_streams.argtypes = []
     L.vtmc_device_results.argtypes = [vp, P(vp), P(vp), P(vp)]
     L.vtmc_reserve_triangles.argtypes = [vp, i64]
     L.vtmc_copy_volume_counts_device.argtypes = [vp, vp, i32, vp]
@@ -153,6 +155,13 @@ def load(path=None):
     if not explicit:
         _lib = L
     return L
+
+
+def release_streams():
+    """vtmc_release_streams: destroys the streams the library keeps parked for contexts that are gone.  Call it once nothing of the host's
+    (events, stream wrappers, pinned tensors copied on them) refers to a handle of a closed Extractor any more -- the tools that run under
+    rocprofv3 do, before they exit."""
+    return _lib.vtmc_release_streams() if _lib is not None else 0
 
 
 def library_path():

@@ -41,16 +41,15 @@ namespace vtmc {
 // referring to them after vtmc_destroy -- events recorded on them, a framework's stream wrapper, a caching allocator that records an event on
 // the stream when it frees a pinned buffer that was copied on it: round 5's aborts in the interpreter's tear-down.  A context therefore does
 // not destroy its streams: vtmc_destroy drains them and parks them here, per device and kind, and the next context on that device takes a
-// parked one.  Bounded by the largest number of contexts alive at once.  AT PROCESS EXIT every stream the library ever made is destroyed by an
-// atexit handler (registered behind the library's first HIP call, so it runs before the HIP runtime's own tear-down): ROCm 7.2's runtime
-// SEGFAULTS in its tear-down when a stream made by hipExtStreamCreateWithCUMask is still alive then (tools/calib/cumask_exit_probe keep,
-// profiles/r06/exit_hang_probes.txt).  VTMC_STREAM_POOL=0 in the environment (test switch) restores destruction in vtmc_destroy.
+// parked one.  Bounded by the largest number of contexts alive at once.  At process exit they are left to the runtime, as a framework's own
+// streams are: an atexit handler that destroyed them (tried in round 6) runs after a profiler's tool library has torn its stream
+// bookkeeping down -- rocprofv3 then aborts inside hipStreamDestroy -- and is not what decides how a process ends under ROCm 7.2 anyway
+// ("Streams": copies on a CU-mask stream do, whatever is destroyed when).  VTMC_STREAM_POOL=0 in the environment (test
+// switch) restores destruction in vtmc_destroy.
 namespace {
 struct StreamPool {
     std::mutex m;
     std::vector<std::pair<int, hipStream_t>> parked[2];   // [0] ordinary non-blocking streams, [1] streams on a hardware queue of their own
-    std::vector<std::pair<int, hipStream_t>> made;        // every stream of either kind that has not been destroyed yet (parked or in a context)
-    bool exit_hook = false;
 };
 StreamPool &stream_pool()
 {
@@ -67,27 +66,14 @@ bool stream_pool_enabled()
     static const bool on = !env_is("VTMC_STREAM_POOL", "0");
     return on;
 }
-void destroy_streams_at_exit()
-{
-    StreamPool &sp = stream_pool();
-    std::lock_guard<std::mutex> g(sp.m);
-    for (auto &ds : sp.made) {
-        if (hipSetDevice(ds.first) != hipSuccess) continue;
-        quiet(hipStreamSynchronize(ds.second));
-        quiet(hipStreamDestroy(ds.second));
-    }
-    sp.made.clear();
-    sp.parked[0].clear();
-    sp.parked[1].clear();
-}
 }  // namespace
 
 // A stream of `device` (current): own_queue = made by hipExtStreamCreateWithCUMask with every CU named -- such a stream always sits on a
 // hardware queue of its own, ordinary streams share a handful (profiles/r05/stream_overlap.txt).
 hipError_t take_stream(int device, bool own_queue, int n_cus, hipStream_t *out)
 {
-    StreamPool &sp = stream_pool();
     if (stream_pool_enabled()) {
+        StreamPool &sp = stream_pool();
         std::lock_guard<std::mutex> g(sp.m);
         auto &v = sp.parked[own_queue ? 1 : 0];
         for (size_t i = v.size(); i-- > 0;)   // the one parked last
@@ -97,39 +83,44 @@ hipError_t take_stream(int device, bool own_queue, int n_cus, hipStream_t *out)
                 return hipSuccess;
             }
     }
-    hipError_t e;
-    if (!own_queue) {
-        e = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
-    } else {
-        std::vector<uint32_t> mask((size_t)(n_cus + 31) / 32, 0xFFFFFFFFu);
-        if (n_cus % 32) mask.back() = (1u << (n_cus % 32)) - 1u;
-        e = hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
-    }
-    if (e == hipSuccess) {
+    if (!own_queue) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    std::vector<uint32_t> mask((size_t)(n_cus + 31) / 32, 0xFFFFFFFFu);
+    if (n_cus % 32) mask.back() = (1u << (n_cus % 32)) - 1u;
+    return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+}
+// every parked stream of every device is destroyed now (vtmc_release_streams); the contexts alive keep theirs
+int release_parked_streams()
+{
+    StreamPool &sp = stream_pool();
+    std::vector<std::pair<int, hipStream_t>> all;
+    {
         std::lock_guard<std::mutex> g(sp.m);
-        sp.made.emplace_back(device, *out);
-        if (!sp.exit_hook) {
-            sp.exit_hook = true;
-            atexit(destroy_streams_at_exit);
+        for (auto &v : sp.parked) {
+            all.insert(all.end(), v.begin(), v.end());
+            v.clear();
         }
     }
-    return e;
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    for (auto &ds : all) {
+        if (hipSetDevice(ds.first) != hipSuccess) continue;
+        quiet(hipStreamSynchronize(ds.second));
+        quiet(hipStreamDestroy(ds.second));
+    }
+    if (have_prev) quiet(hipSetDevice(prev));
+    return (int)all.size();
 }
+
 // the stream is idle (the caller synchronised it)
 void park_stream(int device, bool own_queue, hipStream_t s)
 {
     if (!s) return;
-    StreamPool &sp = stream_pool();
-    std::lock_guard<std::mutex> g(sp.m);
     if (!stream_pool_enabled()) {
-        for (size_t i = 0; i < sp.made.size(); ++i)
-            if (sp.made[i].second == s) {
-                sp.made.erase(sp.made.begin() + (long)i);
-                break;
-            }
         quiet(hipStreamDestroy(s));
         return;
     }
+    StreamPool &sp = stream_pool();
+    std::lock_guard<std::mutex> g(sp.m);
     sp.parked[own_queue ? 1 : 0].emplace_back(device, s);
 }
 
@@ -888,6 +879,11 @@ int32_t vtmc_context_stream(vtmc_ctx *ctx, int32_t own_queue, void **stream)
     }
     *stream = (void *)ctx->queue_stream;
     return VTMC_OK;
+}
+
+int32_t vtmc_release_streams(void)
+{
+    return release_parked_streams();
 }
 
 int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4])

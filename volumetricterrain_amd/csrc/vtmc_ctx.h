@@ -105,6 +105,7 @@ void comm_release(vtmc_ctx *ctx);  // comm.hip: called by vtmc_destroy
 // vtmc_api.hip: a context's streams come from (and return to) a per-device pool and are never destroyed -- see StreamPool there
 hipError_t take_stream(int device, bool own_queue, int n_cus, hipStream_t *out);
 void park_stream(int device, bool own_queue, hipStream_t s);
+int release_parked_streams();
 }  // namespace vtmc
 
 #define VTMC_HIP(ctx, expr)                                                                                \
