@@ -66,6 +66,9 @@ for i, e in enumerate(exs):
     print("context %d: triangles at 0x%012x  (mod 2 MiB %7d, mod 1 GiB %4d MiB)   offsets at 0x%012x   classify med %.4f   emit med %.4f min %.4f"
           % (i, tri, tri % (2 << 20), (tri % (1 << 30)) >> 20, off, statistics.median(r["classify"]), statistics.median(r["emit"]), min(r["emit"])))
 if a.no_realloc:
+    for e in exs:
+        e.close()
+    vt.release_streams()   # profiled (tools/placement_counters.py): no stream of the library's alive when the profiler finalises
     sys.exit(0)
 print("context 0's triangle buffer released and re-reserved (vtmc_reserve_triangles), timed beside context 1:")
 T, _ = step(exs[0])
