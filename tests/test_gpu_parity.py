@@ -693,19 +693,27 @@ def test_rccl_allgather_of_counts_through_the_c_abi(ex, oracle_mod, c, n_vol, pe
             gs = [torch.full((1, per_rank, 2), 0x7FFFFFFF, dtype=torch.int32, device="cuda") for _ in range(2)]
             hosts = [torch.zeros((per_rank, 2), dtype=torch.int32).pin_memory() for _ in range(2)]
             done = [torch.cuda.Event(), torch.cuda.Event()]
+            gathered = [torch.cuda.Event(), torch.cuda.Event()]
+            for e in done:
+                e.record(third)
             torch.cuda.synchronize()
             for route in ("own", "third", "own"):
 
                 def queue(i):
                     k = i % 2
                     cs = sts[k] if route == "own" else third
+                    if route == "own":
+                        sts[k].wait_event(done[k])   # the read-back of the step two before (on `third`) has left gs[k]
                     with torch.cuda.stream(cs):
                         gs[k].fill_(0x7FFFFFFF)     # in front of this step's collective, behind the copy of the step two before
                     ctxs[k].extract_volumes_device_async(d.data_ptr(), (c, c, c), (1, dim, dim * dim), n_vol, dim ** 3, sts[k].cuda_stream)
                     ctxs[k].allgather_volume_counts(gs[k].data_ptr(), per_rank, cs.cuda_stream)
-                    with torch.cuda.stream(cs):
+                    # the pinned read-back never rides an own-queue stream ("Streams"): behind the collective's event on the ordinary one
+                    gathered[k].record(cs)
+                    third.wait_event(gathered[k])
+                    with torch.cuda.stream(third):
                         hosts[k].copy_(gs[k].view(per_rank, 2), non_blocking=True)
-                    done[k].record(cs)
+                    done[k].record(third)
 
                 def take(i):
                     k = i % 2
@@ -722,7 +730,7 @@ def test_rccl_allgather_of_counts_through_the_c_abi(ex, oracle_mod, c, n_vol, pe
                 torch.cuda.synchronize()
             # nothing of torch's may outlive the contexts' streams: PyTorch records an event on every stream a pinned tensor was copied on WHEN IT
             # FREES the tensor, and events / ExternalStream wrappers hold the raw handle
-            del queue, take, sts, done, hosts, gs
+            del queue, take, sts, done, gathered, hosts, gs
             import gc
             gc.collect()
             torch.cuda.synchronize()
