@@ -73,7 +73,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.m
 VALU_PEAK_LANE_OPS = 39.3e12
 
 # the most conservative way to drive the same steps: two contexts taking turns on ONE ordinary stream, every collective behind its emit kernel
-FALLBACK_ARGS = ["--pipeline", "2", "--streams", "1", "--gather-stream", "main", "--assign", "modulo"]
+FALLBACK_ARGS = ["--pipeline", "2", "--streams", "1", "--gather-stream", "main", "--assign", "modulo", "--place-outputs", "0"]
 
 
 def parse(argv=None):
@@ -116,6 +116,11 @@ def parse(argv=None):
                          "alternate between streams and the library chains them by events (csrc/comm.hip); the read-back still travels on an ordinary stream")
     ap.add_argument("--gather-beside", action="store_true",
                     help="N > 1, opt-in: the all-gather on the context's second stream beside the emit kernel (tuning key gather_beside)")
+    ap.add_argument("--place-outputs", type=int, default=8,
+                    help="grid1024: the library's output placement trials (tuning key place_outputs): when a context has just allocated its output buffers -- its first warm-up "
+                         "step -- the emit stage is run into this many candidate allocations and the fastest is kept.  The emit kernel's time is a property of the pair "
+                         "(input field's allocation, output allocation): 0.86 ... 1.00 ms for the identical kernel (profiles/r06/placement_probe.txt).  0 / 1: take what "
+                         "hipMalloc gives (rounds 1-5).  The line reports every candidate's time (output_placement)")
     ap.add_argument("--no-dense", action="store_true", help="A/B: force the per-block classify kernel")
     ap.add_argument("--no-indexed", action="store_true", help="skip the extra indexed-output steps at N = 1")
     ap.add_argument("--no-rehearsal", action="store_true", help="N = 1: skip the rehearsal of every rank of an N = 2 / 4 / 8 run (predicted_scaling)")
@@ -872,6 +877,8 @@ def run_grid(args, torch, dist, wd):
     tuning = None
     if os.environ.get("VTMC_BENCH_TUNING"):   # A/B of kernel variants under the bench's sustained load, e.g. VTMC_BENCH_TUNING="emit_once=0"
         tuning = {k: int(v) for k, v in (item.split("=") for item in os.environ["VTMC_BENCH_TUNING"].split(","))}
+    if args.place_outputs > 1 and not (tuning and "place_outputs" in tuning):
+        tuning = dict(tuning or {}, place_outputs=min(args.place_outputs, 8))
     pipe = GridPipeline(torch, vt, local, depth, args.streams == 2, args.gather_stream, args.gather_beside, tuning, args.no_dense)
     dbg = (lambda m: print("bench.py[%d]: %s" % (rank, m), file=sys.stderr, flush=True)) if os.environ.get("VTMC_BENCH_DEBUG") else (lambda m: None)
     d_field = None
@@ -925,6 +932,13 @@ def run_grid(args, torch, dist, wd):
                 assert np.array_equal(np.diff(offs[:, 1]), costs), "the re-cut world's per-chunk counts differ from the first cut's"
         if n_warm > depth:
             T, offs = pipe.run_steps(n_warm - depth, False, **kw)
+        placement = None
+        if args.place_outputs > 1:
+            trials = [e.last_placement() for e in pipe.exs]
+            placement = {"candidates": min(args.place_outputs, 8),
+                         "emit_ms_by_context": [t[0] for t in trials], "kept": [t[1] for t in trials],
+                         "note": "tuning key place_outputs: at each context's first warm-up step the emit stage was run into this many allocations of the output buffer "
+                                 "and the fastest kept (the emit kernel's time is a property of the pair input allocation / output allocation; candidate 0 is what hipMalloc gave first)"}
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -974,6 +988,7 @@ def run_grid(args, torch, dist, wd):
             "pipeline_depth": depth,
             "streams_mode": "a stream per context, each on a hardware queue of its own (--streams 2)" if pipe.own_queue else "one ordinary stream for every context (--streams 1)",
             "stream_count": len(pipe.streams),
+            "output_placement": placement,
             "fallback": fallback,
         }
         if fallback:
@@ -1301,7 +1316,7 @@ def run_stub(args, wd, spec):
     if rank == 0:
         emit_line({"metric": "stub", "stub": True, "value": 0.0, "unit": "none", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                    "fallback": attempt == 1, "fallback_reason": os.environ.get("VTMC_BENCH_FALLBACK_REASON", ""), "ranks_sum": int(total),
-                   "pipeline_depth": args.pipeline, "streams_arg": args.streams, "gather_stream": args.gather_stream, "assign": args.assign})
+                   "pipeline_depth": args.pipeline, "streams_arg": args.streams, "gather_stream": args.gather_stream, "assign": args.assign, "place_outputs": args.place_outputs})
     wd.stage("teardown", budget)
     maybe_hang("teardown", rank)
     if world > 1:

@@ -94,7 +94,7 @@ def test_supervisor_prints_the_workers_line_once_and_never_imports_torch():
     j = lines[0]
     assert j["stub"] is True and j["value"] == 0.0 and j["fallback"] is False     # a stub line can never pass for a measurement
     assert j["worker"] == {"attempts": 1, "exit_code": 0, "last_stage": "teardown"}
-    assert j["pipeline_depth"] == 4 and j["streams_arg"] == 2 and j["gather_stream"] == "side" and j["assign"] == "balanced"   # the shipped defaults
+    assert j["pipeline_depth"] == 4 and j["streams_arg"] == 2 and j["gather_stream"] == "side" and j["assign"] == "balanced" and j["place_outputs"] == 8   # the shipped defaults
     # the supervisor's own process: bench.py's module level must not pull torch in (a supervisor that touched the GPU could not start a fallback)
     probe = subprocess.run([sys.executable, "-c", "import sys; sys.argv = ['bench.py']; import bench; print('torch' in sys.modules)"], cwd=ROOT,
                            env=_clean_env(), capture_output=True, text=True, timeout=120)
@@ -109,7 +109,7 @@ def test_a_hanging_warmup_costs_its_bound_and_the_fallback_delivers_the_line():
     assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout, p.stderr[-2000:])
     j = lines[0]
     assert j["fallback"] is True and "watchdog in stage 'warmup'" in j["fallback_reason"] and j["worker"]["attempts"] == 2
-    assert j["pipeline_depth"] == 2 and j["streams_arg"] == 1 and j["gather_stream"] == "main" and j["assign"] == "modulo"      # the conservative configuration
+    assert j["pipeline_depth"] == 2 and j["streams_arg"] == 1 and j["gather_stream"] == "main" and j["assign"] == "modulo" and j["place_outputs"] == 0      # the conservative configuration
     assert "WATCHDOG: stage 'warmup' exceeded its bound" in p.stderr and "bench-watchdog" not in p.stdout
     assert "Thread 0x" in p.stderr or "Current thread" in p.stderr          # faulthandler's dump of every thread's stack
 

@@ -35,6 +35,10 @@ def test_single_gpu_line_carries_roofline_and_reproducible_cpu_leg():
     assert "traffic_source" in r and r["region"] == "one_stream"
     assert j["pipeline_depth"] == 4 and j["stream_count"] == 4 and "--streams 2" in j["streams_mode"] and j["step_latency_ms"] > 0      # throughput with four steps in flight on a stream each, isolated-step latency beside it
     assert "ONE stream" in r["measured"] and all(k["isolated_step_ms"] > 0 and k["two_queue_span_ms"] >= k["avg_ms"] * 0.8 for k in j["kernels"].values())
+    # round 6: output placement trials, disclosed: every context's candidates' emit times, the fastest kept
+    op = j["output_placement"]
+    assert op["candidates"] == 8 and len(op["emit_ms_by_context"]) == 4 and all(len(c) == 8 and min(c) > 0 for c in op["emit_ms_by_context"])
+    assert all(c[k] == min(c) for c, k in zip(op["emit_ms_by_context"], op["kept"]))
     # round 6: the box's own memory rates (a fresh process after the timed regions) and the kernels' rates as fractions of them
     b = j["box"]
     assert "error" not in b, b
@@ -153,4 +157,5 @@ def test_a_worker_that_hangs_on_the_gpu_is_replaced_by_the_conservative_one():
     j = lines[0]
     assert j["fallback"] is True and "watchdog in stage 'warmup'" in j["fallback_reason"] and j["worker"]["attempts"] == 2
     assert j["pipeline_depth"] == 2 and j["stream_count"] == 1 and j["value"] > 0 and abs(j["triangles_total"] - 2655156) < 2000
+    assert j["output_placement"] is None          # the conservative configuration takes what hipMalloc gives
     assert "WATCHDOG: stage 'warmup'" in p.stderr

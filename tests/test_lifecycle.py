@@ -246,3 +246,36 @@ def test_torch_objects_on_a_contexts_stream_may_outlive_the_context(oracle_mod):
     assert vt.release_streams() == 0
     with vt.Extractor(0) as ex2:              # the next context simply makes new streams
         assert ex2.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 1, dim ** 3, ex2.stream_handle(own_queue=True)) == want
+
+
+def test_output_placement_keeps_the_fastest_candidate_and_the_whole_result(oracle_mod):
+    """Tuning key place_outputs: at a (re)allocation of the output buffers the emit stage is run into K allocations and the fastest kept --
+    the result is complete and identical whichever candidate wins, the report says what was tried, a later extract (no new allocation) tries
+    nothing, a growth tries again; the same in the indexed format."""
+    import torch
+    import volumetricterrain_amd as vt
+    c, dim = 64, 66
+    g = oracle_mod.density_volume("perlin3d", c)
+    want, want_offs, _ = oracle_mod.extract_grid(g, threads=4)
+    d = torch.from_numpy(np.ascontiguousarray(g.transpose(2, 1, 0))).cuda()
+    with vt.Extractor(0) as ex:
+        assert ex.last_placement() == ([], 0)
+        ex.set_tuning(place_outputs=3)
+        ex.reserve_triangles(len(want) + 10)                      # a new allocation: the next extract places it
+        assert ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 1, dim ** 3) == len(want)
+        ms, kept = ex.last_placement()
+        assert len(ms) == 3 and all(m > 0 for m in ms) and ms[kept] == min(ms)
+        got, offs = ex.read_triangles()
+        assert np.array_equal(offs, want_offs) and np.array_equal(got["block"], want["block"])
+        assert max(float(np.abs(got[f] - want[f]).max()) for f in ("p0", "p1", "p2", "n0", "n1", "n2")) <= 1e-5
+        assert ex.last_stage_ms()["emit"] == pytest.approx(ms[kept], rel=1e-3)
+        ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 1, dim ** 3)
+        assert ex.last_placement() == (ms, kept)                  # nothing was allocated: nothing was tried
+        ex.set_output_mode(True)                                  # the indexed buffers are allocated at their first use: a trial of their own
+        ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 1, dim ** 3)
+        ms_i, kept_i = ex.last_placement()
+        assert len(ms_i) == 3 and ms_i != ms and ms_i[kept_i] == min(ms_i)
+        verts, idx, voffs, toffs = ex.read_indexed_mesh()
+        wv, wi, wvo, wto = oracle_mod.extract_grid_indexed(g)
+        assert np.array_equal(idx, wi) and np.array_equal(voffs, wvo) and np.array_equal(toffs, wto)
+        assert float(np.abs(verts["position"] - wv["position"]).max()) <= 1e-5

@@ -17,7 +17,7 @@ from test_gpu_parity import assert_tris_match
 pytestmark = pytest.mark.gpu
 
 DEFAULTS = dict(emit_fast_math=1, emit_once=1, emit_dynamic=1, emit_sub_log2=1, emit_row_masks=1, emit_wgs_per_cu=0,
-                classify_wgs_per_cu=3, stage_events=1, gather_beside=0, fill_keeps_signs=0, density_wgs_per_cu=0)
+                classify_wgs_per_cu=3, stage_events=1, gather_beside=0, fill_keeps_signs=0, density_wgs_per_cu=0, place_outputs=0)
 
 # (tuning, runs in soup mode, runs in indexed mode)
 SETS = [
@@ -42,6 +42,10 @@ SETS = [
     (dict(classify_wgs_per_cu=4), True, False),
     (dict(classify_wgs_per_cu=7), True, False),
     (dict(stage_events=0), True, True),
+    # round 6: output placement trials (the emit stage run into several allocations, the fastest kept): every candidate holds the complete result
+    (dict(place_outputs=2), True, True),
+    (dict(place_outputs=4, emit_once=0), True, False),
+    (dict(place_outputs=8, stage_events=0), True, True),
 ]
 
 

@@ -21,6 +21,7 @@ ap.add_argument("--field-first", action="store_true", help="allocate the density
 ap.add_argument("--tune", default="", help="key=value,... for every context")
 ap.add_argument("--no-realloc", action="store_true")
 ap.add_argument("--lib", default=None, help="another build of the library (path)")
+ap.add_argument("--fields", type=int, default=0, help="also: this many COPIES of the input field at other addresses, every context timed on every copy")
 a = ap.parse_args()
 n, c, dim = 1024, 128, 130
 org = sharding.chunk_origins(n, c)
@@ -65,6 +66,19 @@ for i, e in enumerate(exs):
     r = res[id(e)]
     print("context %d: triangles at 0x%012x  (mod 2 MiB %7d, mod 1 GiB %4d MiB)   offsets at 0x%012x   classify med %.4f   emit med %.4f min %.4f"
           % (i, tri, tri % (2 << 20), (tri % (1 << 30)) >> 20, off, statistics.median(r["classify"]), statistics.median(r["emit"]), min(r["emit"])))
+if a.fields:
+    # is a level a property of the output buffer alone, or of the pair (input field, output buffer)?
+    copies = [d] + [d.clone() for _ in range(a.fields)]
+    print("every context on %d copies of the field (rows: contexts, columns: the field at %s); emit med ms" % (len(copies), " ".join("0x%x" % c_.data_ptr() for c_ in copies)))
+    table = {(i, k): [] for i in range(len(exs)) for k in range(len(copies))}
+    for _ in range(a.rounds):
+        for k, dk in enumerate(copies):
+            for i, e in enumerate(exs):
+                e.extract_volumes_device(dk.data_ptr(), (c, c, c), (1, dim, dim * dim), len(org), dim ** 3)
+                table[(i, k)].append(e.last_stage_ms()["emit"])
+    for i in range(len(exs)):
+        print("  context %d: %s" % (i, "  ".join("%.4f" % statistics.median(table[(i, k)]) for k in range(len(copies)))))
+    del copies
 if a.no_realloc:
     for e in exs:
         e.close()

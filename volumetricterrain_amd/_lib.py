@@ -36,7 +36,7 @@ SYMBOLS = [
     "vtmc_set_output_mode", "vtmc_last_vertex_count", "vtmc_read_indexed_mesh", "vtmc_device_indexed_results",
     "vtmc_comm_unique_id", "vtmc_comm_init_rank", "vtmc_comm_destroy", "vtmc_comm_share", "vtmc_allgather_volume_counts",
     "vtmc_copy_to_host", "vtmc_chunk_write", "vtmc_chunk_read",
-    "vtmc_extract_volumes_device_async", "vtmc_extract_finish", "vtmc_last_fill_ms", "vtmc_context_stream", "vtmc_release_streams",
+    "vtmc_extract_volumes_device_async", "vtmc_extract_finish", "vtmc_last_fill_ms", "vtmc_context_stream", "vtmc_release_streams", "vtmc_last_placement",
 ]
 COMM_ID_BYTES = 128
 
@@ -121,6 +121,8 @@ def load(path=None):
         L.vtmc_context_stream.argtypes = [vp, i32, P(vp)]
     if not explicit or hasattr(L, "vtmc_release_streams"):
         L.vtmc_release_streams.argtypes = []
+    if not explicit or hasattr(L, "vtmc_last_placement"):
+        L.vtmc_last_placement.argtypes = [vp, P(ctypes.c_float * 8), P(i32), P(i32)]
     L.vtmc_device_results.argtypes = [vp, P(vp), P(vp), P(vp)]
     L.vtmc_reserve_triangles.argtypes = [vp, i64]
     L.vtmc_copy_volume_counts_device.argtypes = [vp, vp, i32, vp]

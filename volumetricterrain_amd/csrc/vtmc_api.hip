@@ -231,8 +231,10 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
         return fail(ctx, VTMC_ERR_TOO_LARGE, "strides too large: a 10x10x10 tile must span less than 4 GiB");
     if (int rc = ensure(ctx, ctx->offsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
     if (int rc = ensure(ctx, ctx->volcounts, sizeof(uint32_t) * 2 * (size_t)std::max(n_volumes, 1))) return rc;
-    if (!indexed && !ctx->tris.p)
+    if (!indexed && !ctx->tris.p) {
         if (int rc = ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * ((size_t)1 << 20))) return rc;
+        ctx->place_pending = true;
+    }
     if (int rc = ensure(ctx, ctx->counts, sizeof(uint32_t) * (size_t)B)) return rc;
     if (int rc = ensure(ctx, ctx->active, sizeof(BlockDesc) * (size_t)B)) return rc;   // one record per non-empty block, written by the scan
     if (B >= (1 << 30)) return fail(ctx, VTMC_ERR_TOO_LARGE, "more than 2^30 blocks in one batch");   // the scan's status word holds 30 bits of non-empty blocks
@@ -249,10 +251,14 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
         if (int rc = ensure(ctx, ctx->vcounts, sizeof(uint32_t) * (size_t)B)) return rc;
         if (int rc = ensure(ctx, ctx->voffsets, sizeof(uint32_t) * ((size_t)B + 1))) return rc;
         if (int rc = ensure(ctx, ctx->vtotals, sizeof(uint32_t) * 64)) return rc;
-        if (!ctx->verts.p)
+        if (!ctx->verts.p) {
             if (int rc = ensure(ctx, ctx->verts, sizeof(vtmc_vertex) * ((size_t)1 << 19))) return rc;
-        if (!ctx->indices.p)
+            ctx->place_pending = true;
+        }
+        if (!ctx->indices.p) {
             if (int rc = ensure(ctx, ctx->indices, sizeof(int32_t) * 3 * ((size_t)1 << 20))) return rc;
+            ctx->place_pending = true;
+        }
         d_vcounts = (uint32_t *)ctx->vcounts.p;
     }
     // the streaming classify wants 32+ cells along the stride-1 axis: x, or z for the C# float[,,] order
@@ -297,6 +303,75 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
     return rc;
 }
 
+// OUTPUT PLACEMENT (tuning key place_outputs = K > 1; round 6).  The emit kernel's time is a property of the pair (input field's allocation,
+// output buffers' allocation): the identical kernel on the identical input runs 0.86 / 0.91 / 0.96 / 1.00 ms by which allocation it writes
+// (profiles/r06/placement_probe.txt; the slow levels are +10 % memory latency for the identical request stream).  Which bits decide it is not
+// established, so the library does what an autotuner does: when the output buffers have just been (re)allocated -- the first extract of a
+// context, a growth -- the emit stage of the extract at hand is run into K - 1 further allocations of the same size, each timed, and the
+// fastest set is kept (the others are freed).  Every run writes the complete, identical result; the extract's own result is in whatever set
+// is kept.  Cost: K - 1 emit launches and allocations, once per (re)allocation.
+int place_outputs(vtmc_ctx *ctx)
+{
+    const VtmcPending &pe = ctx->pending;
+    const int K = std::min(ctx->tune.place_outputs, 8);
+    // the buffers the emit stage of this extract writes: the triangle records, or (indexed output) the index and vertex buffers
+    DevBuf &A = pe.indexed ? ctx->indices : ctx->tris;
+    DevBuf none;
+    DevBuf &B = pe.indexed ? ctx->verts : none;
+    struct Set { DevBuf a, b; float ms = 0.f; };
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    VTMC_HIP(ctx, hipEventCreate(&t0));
+    VTMC_HIP(ctx, hipEventCreate(&t1));
+    auto timed_emit = [&](float *ms) -> int {   // the emit stage into the context's current buffers, twice: the second run's time counts
+        for (int rep = 0; rep < 2; ++rep) {
+            VTMC_HIP(ctx, hipEventRecord(t0, pe.stream));
+            if (int rc = queue_emit(ctx, true)) return rc;
+            VTMC_HIP(ctx, hipEventRecord(t1, pe.stream));
+            VTMC_HIP(ctx, hipEventSynchronize(t1));
+            VTMC_HIP(ctx, hipEventElapsedTime(ms, t0, t1));
+        }
+        return VTMC_OK;
+    };
+    auto take = [&](Set &st) { st.a = A; st.b = B; A = DevBuf{}; B = DevBuf{}; };
+    ctx->place_n = 0;
+    ctx->place_kept = 0;
+    Set best;
+    int rc = timed_emit(&best.ms);
+    if (!rc) {
+        ctx->place_ms[ctx->place_n++] = best.ms;
+        take(best);
+        for (int k = 1; k < K; ++k) {
+            // a further allocation of the same sizes WHILE the ones before it are still held: another place in memory
+            int e = ensure(ctx, A, best.a.bytes);
+            if (!e && pe.indexed) e = ensure(ctx, B, best.b.bytes);
+            Set cand;
+            if (!e) e = timed_emit(&cand.ms);
+            if (e) {   // out of memory, or a launch that failed: the trial ends here and the best so far stays
+                quiet(hipStreamSynchronize(pe.stream));
+                release(A);
+                release(B);
+                ctx->err.clear();
+                break;
+            }
+            ctx->place_ms[ctx->place_n++] = cand.ms;
+            take(cand);
+            if (cand.ms < best.ms) {
+                std::swap(cand, best);
+                ctx->place_kept = k;
+            }
+            release(cand.a);   // the loser
+            release(cand.b);
+        }
+        A = best.a;
+        B = best.b;
+    }
+    quiet(hipEventDestroy(t0));
+    quiet(hipEventDestroy(t1));
+    if (rc) return rc;
+    VTMC_HIP(ctx, hipStreamSynchronize(pe.stream));   // the kept buffers hold a complete result (every candidate was emitted in full)
+    return VTMC_OK;
+}
+
 // Completes a queued extract: waits for the stream, reads {T, V} from pinned memory and -- when the
 // emit kernel found its buffers too small and did not run -- grows them (with head-room, so a slowly
 // changing field does not regrow every frame) and queues only the emit stage again.
@@ -334,12 +409,21 @@ int extract_finish(vtmc_ctx *ctx, int64_t *tri_count)
             if ((size_t)T > ctx->pending.tcap) {
                 const size_t want = (size_t)T + (size_t)T / 8 + 1024;
                 if (int rc = pe.indexed ? ensure(ctx, ctx->indices, sizeof(int32_t) * 3 * want) : ensure(ctx, ctx->tris, sizeof(vtmc_triangle) * want)) return rc;
+                ctx->place_pending = true;
             }
-            if ((size_t)V > ctx->pending.vcap)
+            if ((size_t)V > ctx->pending.vcap) {
                 if (int rc = ensure(ctx, ctx->verts, sizeof(vtmc_vertex) * ((size_t)V + (size_t)V / 8 + 1024))) return rc;
+                ctx->place_pending = true;
+            }
             VTMC_HIP(ctx, hipEventRecord(ctx->ev[2], pe.stream));
             if (int rc = queue_emit(ctx, true)) return rc;
         }
+        bool placed = false;
+        if (ctx->place_pending && ctx->tune.place_outputs > 1 && T_found > 0) {
+            if (int rc = place_outputs(ctx)) return rc;
+            placed = ctx->place_n > 0;
+        }
+        ctx->place_pending = false;
         float a = 0, b = 0, c = 0;
         if (ctx->tune.stage_events) {
             VTMC_HIP(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
@@ -348,6 +432,10 @@ int extract_finish(vtmc_ctx *ctx, int64_t *tri_count)
             ctx->stage_ms[3] = a + b + c;
         } else {
             VTMC_HIP(ctx, hipEventElapsedTime(&ctx->stage_ms[3], ctx->ev[0], ctx->ev[3]));
+        }
+        if (placed) {   // ev[3] stands behind the last candidate's launch: this extract's emit stage is the kept candidate's run
+            c = ctx->place_ms[ctx->place_kept];
+            ctx->stage_ms[3] = a + b + c;
         }
         ctx->stage_ms[0] = a;
         ctx->stage_ms[1] = b;
@@ -852,7 +940,10 @@ int32_t vtmc_reserve_triangles(vtmc_ctx *ctx, int64_t capacity)
     ctx->has_result = false;  // the old triangle buffer may be released
     const size_t bytes = sizeof(vtmc_triangle) * (size_t)std::max<int64_t>(capacity, 1);
     if (ctx->tris.p && ctx->tris.bytes > std::max<size_t>(bytes, 256)) release(ctx->tris);  // exact size: shrinking is allowed
-    return ensure(ctx, ctx->tris, bytes);
+    const void *before = ctx->tris.p;
+    const int rc = ensure(ctx, ctx->tris, bytes);
+    if (!rc && ctx->tris.p != before) ctx->place_pending = true;   // a new allocation: the next extract may try others beside it (place_outputs)
+    return rc;
 }
 
 int32_t vtmc_context_stream(vtmc_ctx *ctx, int32_t own_queue, void **stream)
@@ -878,6 +969,15 @@ int32_t vtmc_context_stream(vtmc_ctx *ctx, int32_t own_queue, void **stream)
         }
     }
     *stream = (void *)ctx->queue_stream;
+    return VTMC_OK;
+}
+
+int32_t vtmc_last_placement(const vtmc_ctx *ctx, float ms[8], int32_t *n_candidates, int32_t *kept)
+{
+    if (!ctx) return VTMC_ERR_INVALID_ARG;
+    if (ms) memcpy(ms, ctx->place_ms, sizeof ctx->place_ms);
+    if (n_candidates) *n_candidates = ctx->place_n;
+    if (kept) *kept = ctx->place_kept;
     return VTMC_OK;
 }
 
@@ -916,6 +1016,7 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     if (k == "classify_wgs_per_cu") return ranged(ctx->tune.classify_wgs_per_cu, 0, 7);
     if (k == "density_wgs_per_cu") return ranged(ctx->tune.density_wgs_per_cu, 0, 3);
     if (k == "gather_beside") return ranged(ctx->tune.gather_beside, 0, 1);
+    if (k == "place_outputs") return ranged(ctx->tune.place_outputs, 0, 8);
     if (k == "stage_events") return ranged(ctx->tune.stage_events, 0, 1);
     if (k == "invalidate_signs") {   // the caller wrote to (or re-used the address of) a buffer the last fill left sign bits for
         ctx->sign_of.valid = false;

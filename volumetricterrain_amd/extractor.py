@@ -240,6 +240,12 @@ class Extractor:
         self._check(self._L.vtmc_last_stage_ms(self._h, ctypes.byref(ms)))
         return {"classify": ms[0], "scan": ms[1], "emit": ms[2], "total": ms[3]}
 
+    def last_placement(self):
+        """The last output-placement trial (tuning key place_outputs): ([emit ms per candidate], index kept); ([], 0) when none has run."""
+        ms, n, kept = (ctypes.c_float * 8)(), ctypes.c_int32(), ctypes.c_int32()
+        self._check(self._L.vtmc_last_placement(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(kept)))
+        return [round(float(ms[i]), 4) for i in range(n.value)], kept.value
+
     def last_fill_ms(self):
         ms = ctypes.c_float()
         self._check(self._L.vtmc_last_fill_ms(self._h, ctypes.byref(ms)))
