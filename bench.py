@@ -757,7 +757,7 @@ def rehearse_ranks(torch, pipe, d_field, n_chunks_world, chunk, chunk_tris, chun
         want = int(sum(int(chunk_tris[c]) for c in ids))
         assert T == want and int(offs[-1, 1]) == want, "rehearsal: rank's triangle total %d, its chunks' counts say %d" % (T, want)
         best = None
-        for _ in range(2):
+        for _ in range(3):   # the best of three regions: one rank in ten draws a region 5 % slow
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             pipe.run_steps(steps, False)

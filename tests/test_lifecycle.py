@@ -268,7 +268,7 @@ def test_output_placement_keeps_the_fastest_candidate_and_the_whole_result(oracl
         got, offs = ex.read_triangles()
         assert np.array_equal(offs, want_offs) and np.array_equal(got["block"], want["block"])
         assert max(float(np.abs(got[f] - want[f]).max()) for f in ("p0", "p1", "p2", "n0", "n1", "n2")) <= 1e-5
-        assert ex.last_stage_ms()["emit"] == pytest.approx(ms[kept], rel=1e-3)
+        assert ex.last_stage_ms()["emit"] == pytest.approx(ms[kept], abs=1e-4)          # the report is rounded to four decimals
         ex.extract_volumes_device(d.data_ptr(), (c, c, c), (1, dim, dim * dim), 1, dim ** 3)
         assert ex.last_placement() == (ms, kept)                  # nothing was allocated: nothing was tried
         ex.set_output_mode(True)                                  # the indexed buffers are allocated at their first use: a trial of their own

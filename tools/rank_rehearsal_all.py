@@ -50,7 +50,7 @@ def rehearse(depth, own_queue, gather_stream, assign):
 
 
 print("RANK REHEARSAL, EVERY RANK (round 6; tools/rank_rehearsal_all.py, one process, one GPU: %s)" % torch.cuda.get_device_name(0))
-print("perlin3d 1024^3 as 512 chunks of 128^3; ms per step, best of two regions of %d steps; T and the gathered counts checked for every rank" % a.steps)
+print("perlin3d 1024^3 as 512 chunks of 128^3; ms per step, best of three regions of %d steps; T and the gathered counts checked for every rank" % a.steps)
 for label, depth, own, gs in (("SHIPPED N > 1 DEFAULT: 4 steps in flight, a hardware queue per context, collectives on ONE ordinary stream (--gather-stream %s)" % a.gather_stream, 4, True, a.gather_stream),
                               ("FALLBACK: 2 steps in flight on one ordinary stream, every collective behind its emit kernel", 2, False, "main")):
     for assign in ("modulo", "balanced"):
