@@ -35,7 +35,7 @@ raw = {}
 
 
 def rehearse(depth, own_queue, gather_stream, assign):
-    pipe = bench.GridPipeline(torch, vt, 0, depth, own_queue, gather_stream)
+    pipe = bench.GridPipeline(torch, vt, 0, depth, own_queue, gather_stream, tuning={"place_outputs": 8} if own_queue else None)   # as bench.py: placement trials in the default, none in the fallback
     try:
         pipe.exs[0].density_fill_device(vt.density_params("perlin3d", n), sharding.origins_of(n, c, range(n_chunks)), (dim, dim, dim), (1, dim, dim * dim),
                                         dim ** 3, d_field.data_ptr(), pipe.streams[0].cuda_stream)
@@ -51,7 +51,8 @@ def rehearse(depth, own_queue, gather_stream, assign):
 
 print("RANK REHEARSAL, EVERY RANK (round 6; tools/rank_rehearsal_all.py, one process, one GPU: %s)" % torch.cuda.get_device_name(0))
 print("perlin3d 1024^3 as 512 chunks of 128^3; ms per step, best of three regions of %d steps; T and the gathered counts checked for every rank" % a.steps)
-for label, depth, own, gs in (("SHIPPED N > 1 DEFAULT: 4 steps in flight, a hardware queue per context, collectives on ONE ordinary stream (--gather-stream %s)" % a.gather_stream, 4, True, a.gather_stream),
+for label, depth, own, gs in ((("SHIPPED N > 1 DEFAULT: 4 steps in flight, a hardware queue per context, every collective on ONE ordinary stream (--gather-stream side)" if a.gather_stream == "side" else
+                               "4 steps in flight, a hardware queue per context, every collective behind its emit kernel on the step's own stream (--gather-stream main)"), 4, True, a.gather_stream),
                               ("FALLBACK: 2 steps in flight on one ordinary stream, every collective behind its emit kernel", 2, False, "main")):
     for assign in ("modulo", "balanced"):
         r, tris, active = rehearse(depth, own, gs, assign)
