@@ -207,8 +207,8 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value);
  * input field, allocation of the output buffers): the identical kernel on the identical input runs 0.86 ... 1.00 ms by which allocation it
  * writes (profiles/r06/placement_probe.txt).  With K > 1, whenever the library has just (re)allocated its output buffers -- a context's first
  * extract, a growth -- it runs the emit stage of the extract at hand into K - 1 further allocations of the same size, times each and keeps the
- * fastest (an autotuner's move; the result is complete and identical in every candidate).  Cost: K - 1 emit launches, K - 1 transient
- * allocations, once per (re)allocation.  vtmc_last_placement reports the last trial: the emit stage's milliseconds per candidate (ms[0] = the
+ * fastest (an autotuner's move; the result is complete and identical in every candidate).  Cost: 2 (K - 1) emit launches and K allocations of the
+ * output held at once while the trial runs (they must differ: one freed and made again gets its old pages back), once per (re)allocation.  vtmc_last_placement reports the last trial: the emit stage's milliseconds per candidate (ms[0] = the
  * allocation that was there), how many were tried (0: no trial yet) and which one was kept. */
 int32_t vtmc_last_placement(const vtmc_ctx *ctx, float ms[8], int32_t *n_candidates, int32_t *kept);
 

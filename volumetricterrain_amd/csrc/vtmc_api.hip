@@ -309,7 +309,7 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
 // established, so the library does what an autotuner does: when the output buffers have just been (re)allocated -- the first extract of a
 // context, a growth -- the emit stage of the extract at hand is run into K - 1 further allocations of the same size, each timed, and the
 // fastest set is kept (the others are freed).  Every run writes the complete, identical result; the extract's own result is in whatever set
-// is kept.  Cost: K - 1 emit launches and allocations, once per (re)allocation.
+// is kept.  Cost: 2 (K - 1) emit launches, and K allocations of the output held at once while the trial runs, once per (re)allocation.
 int place_outputs(vtmc_ctx *ctx)
 {
     const VtmcPending &pe = ctx->pending;
@@ -336,12 +336,13 @@ int place_outputs(vtmc_ctx *ctx)
     ctx->place_n = 0;
     ctx->place_kept = 0;
     Set best;
+    std::vector<Set> losers;   // held until the trial ends: an allocation made while the earlier ones are alive is another place in memory; one made
+                               // after a loser was freed gets the loser's pages back (round 6's first form: runs of identical times)
     int rc = timed_emit(&best.ms);
     if (!rc) {
         ctx->place_ms[ctx->place_n++] = best.ms;
         take(best);
         for (int k = 1; k < K; ++k) {
-            // a further allocation of the same sizes WHILE the ones before it are still held: another place in memory
             int e = ensure(ctx, A, best.a.bytes);
             if (!e && pe.indexed) e = ensure(ctx, B, best.b.bytes);
             Set cand;
@@ -359,8 +360,11 @@ int place_outputs(vtmc_ctx *ctx)
                 std::swap(cand, best);
                 ctx->place_kept = k;
             }
-            release(cand.a);   // the loser
-            release(cand.b);
+            losers.push_back(cand);
+        }
+        for (Set &l : losers) {
+            release(l.a);
+            release(l.b);
         }
         A = best.a;
         B = best.b;
