@@ -71,13 +71,18 @@ if a.fields:
     copies = [d] + [d.clone() for _ in range(a.fields)]
     print("every context on %d copies of the field (rows: contexts, columns: the field at %s); emit med ms" % (len(copies), " ".join("0x%x" % c_.data_ptr() for c_ in copies)))
     table = {(i, k): [] for i in range(len(exs)) for k in range(len(copies))}
+    ctab = {(i, k): [] for i in range(len(exs)) for k in range(len(copies))}
     for _ in range(a.rounds):
         for k, dk in enumerate(copies):
             for i, e in enumerate(exs):
                 e.extract_volumes_device(dk.data_ptr(), (c, c, c), (1, dim, dim * dim), len(org), dim ** 3)
                 table[(i, k)].append(e.last_stage_ms()["emit"])
+                ctab[(i, k)].append(e.last_stage_ms()["classify"])
     for i in range(len(exs)):
         print("  context %d: %s" % (i, "  ".join("%.4f" % statistics.median(table[(i, k)]) for k in range(len(copies)))))
+    print("the classify kernel on the same copies (one read stream over the field: does IT care where the field lies?)")
+    for i in range(len(exs)):
+        print("  context %d: %s" % (i, "  ".join("%.4f" % statistics.median(ctab[(i, k)]) for k in range(len(copies)))))
     del copies
 if a.no_realloc:
     for e in exs:
