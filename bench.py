@@ -17,7 +17,9 @@ contexts take turns, each on its own-queue stream, and step k + 3 is queued befo
 k's T and offsets, so the device goes from step to step without waiting for the host -- the way a host
 that extracts frame after frame would drive the library; every step still delivers its T, gather and
 offsets.  `value` is that throughput; the latency of an isolated step is reported next to it
-(`step_latency_ms`, = --pipeline 1).
+(`step_latency_ms`, = --pipeline 1).  Each context's output buffer is chosen among eight allocations in its first
+warm-up step (--place-outputs 8: the library's placement trials; the identical emit kernel runs 0.86 ... 1.00 ms
+by which allocation it writes, profiles/r06/placement_probe.txt; every candidate's time is in the line).
 
 --config stream2048 (BASELINE.json configs[4]): a 2048^3-cell fbm8 world (36 GB of samples) streamed
 as double-buffered batches of 128^3 chunks (two density buffers / contexts, each on its own-queue
