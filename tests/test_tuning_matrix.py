@@ -143,7 +143,8 @@ def test_refused_keys_and_values(ex):
     for key, value in (("one_pass", 1), ("one_pass_depth", 2), ("one_pass_unit", 1), ("one_pass_prefetch", 1), ("emit_async", 0),
                        ("emit_group_log2", 2), ("emit_ablate", 1), ("classify_ablate", 1), ("density_ablate", 1), ("no_such_key", 0),
                        ("emit_idx_waves", 3), ("emit_idx_waves", 4), ("classify_wide", 1), ("emit_sub_log2", 5), ("emit_sub_log2", -1), ("emit_wgs_per_cu", 9),
-                       ("classify_wgs_per_cu", 8), ("classify_wgs_per_cu", 1), ("density_wgs_per_cu", 1), ("density_wgs_per_cu", 4), ("emit_fast_math", 2), ("emit_once", -1)):
+                       ("classify_wgs_per_cu", 8), ("classify_wgs_per_cu", 1), ("density_wgs_per_cu", 1), ("density_wgs_per_cu", 4), ("emit_fast_math", 2), ("emit_once", -1), ("place_outputs", 9), ("place_outputs", -1),
+                       ("classify_column", 4), ("classify_column_wgs", 2)):
         with pytest.raises(vt.VtmcError) as e:
             ex.set_tuning(**{key: value})
         assert e.value.code == -1, key   # VTMC_ERR_INVALID_ARG
