@@ -128,6 +128,7 @@ def parse(argv=None):
     ap.add_argument("--no-rehearsal", action="store_true", help="N = 1: skip the rehearsal of every rank of an N = 2 / 4 / 8 run (predicted_scaling)")
     ap.add_argument("--no-stream-record", action="store_true", help="N = 1: skip the short stream2048 run behind the grid (the `stream2048` sub-record)")
     ap.add_argument("--stream-record-cells", type=int, default=2048, help="cells per axis of the `stream2048` sub-record (reduced sizes for tests)")
+    ap.add_argument("--no-terrain-record", action="store_true", help="N = 1: skip the `terrain` sub-record (world build + interactive edits on a grid resident in HBM: SURVEY 8f rank 1)")
     ap.add_argument("--no-box", action="store_true", help="skip the memory calibration of this box (tools/calib/mix2 box, a fresh process after the timed regions)")
     ap.add_argument("--no-fallback", action="store_true", help="a failed worker is not followed by a second, conservative attempt")
     ap.add_argument("--direct", action="store_true", help="no supervisor: measure in this process (for profilers; no fallback, the watchdog still applies)")
@@ -859,6 +860,51 @@ def stream_sub_record(torch, args, local):
                                                "scan": round(m["stage"]["scan"], 3), "emit_kernel": round(m["stage"]["emit"], 3)}}
 
 
+def terrain_sub_record(vt):
+    """SURVEY 8f rank 1 in the driver's own run: the density grid resident in HBM, VoxelTerrain.Update on the device.  (a) the world build as
+    TerrainEngine.Init does it (TerrainEngine.cs:87-99): 1024 x 256 x 1024 cells, one IslandModifier (512^2 heightmap) + 40 river cylinders, ONE
+    vtmc_terrain_update (density write of every modifier + extraction of every block); (b) the interactive edit of SceneManager.cs:121-129 on
+    the demo world (256 x 72 x 256): 200 sphere edits r = 10, one vtmc_terrain_update each (density write + dirty set + classify + scan +
+    emit + T on the host).  Wall clock around the blocking calls; the CPU side of both is tools/world_build_bench.py / tools/edit_latency.py."""
+    rng = np.random.default_rng(3)
+    W, E, H = 1024, 256, 1024
+    u = np.linspace(-1, 1, 512, dtype=np.float32)[:, None]
+    v = np.linspace(-1, 1, 512, dtype=np.float32)[None, :]
+    hm = (0.55 * np.exp(-2.5 * (u * u + v * v)) + 0.06 * np.sin(7 * u) * np.cos(5 * v) + 0.12).astype(np.float32)
+    owners = [vt.IslandModifier(hm * E, float(W), float(H), float(E), True)]
+    for _ in range(40):
+        start = (float(rng.uniform(0.2, 0.8) * W), float(rng.uniform(0.25, 0.5) * E), float(rng.uniform(0.2, 0.8) * H))
+        d = (float(rng.normal()), float(rng.normal() * 0.1), float(rng.normal()))
+        owners.append(vt.CylinderModifier(start, d, float(rng.uniform(0.05, 0.15) * W), float(rng.uniform(1.5, 3.0)), False))
+    mods = [m.to_struct() for m in owners]   # the structs borrow the heightmap array: `owners` stays alive
+    with vt.Extractor(0) as ex:
+        times = []
+        for _ in range(4):
+            ex.terrain_init(W, E, H, 1.0, (0.0, 0.0, 0.0), 5)
+            t0 = time.perf_counter()
+            nd, T = ex.terrain_update(mods)
+            times.append(time.perf_counter() - t0)
+        build = {"world": "%dx%dx%d cells, IslandModifier (512^2 heightmap) + 40 river cylinders, one Update" % (W, E, H),
+                 "update_ms": round(min(times[1:]) * 1e3, 3), "dirty_blocks": int(nd), "triangles": int(T),
+                 "msamples_per_s": round((W + 2) * (E + 2) * (H + 2) / min(times[1:]) / 1e6, 1)}
+    erng = np.random.default_rng(1)
+    with vt.Extractor(0) as ex:
+        ex.terrain_init(256, 72, 256, 1.0, (0.0, 0.0, 0.0), 1)
+        ex.terrain_update([vt.PlaneModifier(30.5, (-1, -1), (300, 300), True)])
+        lat, tris = [], []
+        for i in range(220):
+            cpos = (float(erng.uniform(20, 236)), 30.0 + float(erng.uniform(-4, 4)), float(erng.uniform(20, 236)))
+            m = vt.SphereModifier(cpos, 10.0, bool(i & 1))
+            t0 = time.perf_counter()
+            nd, T = ex.terrain_update([m])
+            if i >= 20:
+                lat.append((time.perf_counter() - t0) * 1e6)
+                tris.append(T)
+        edits = {"world": "256x72x256 cells, plane + 200 sphere edits r = 10 (alternating add / erode)", "edit_latency_us_median": round(statistics.median(lat), 1),
+                 "edit_latency_us_p90": round(float(np.percentile(lat, 90)), 1), "triangles_median": int(statistics.median(tris))}
+    return {"world_build": build, "edits": edits}
+
+
 def run_grid(args, torch, dist, wd):
     import volumetricterrain_amd as vt
     from volumetricterrain_amd import sharding
@@ -1178,6 +1224,16 @@ def run_grid(args, torch, dist, wd):
                 out["stream2048"] = {"error": "%s: %s" % (type(e).__name__, e)}
         else:
             out["stream2048"] = None
+        if world == 1 and not args.no_terrain_record:
+            wd.stage("terrain_record", 240)
+            emit_partial(out, "the terrain sub-record is missing: the worker ended before it sent the full line")
+            try:
+                import volumetricterrain_amd as vt_
+                out["terrain"] = terrain_sub_record(vt_)
+            except Exception as e:   # noqa: BLE001
+                out["terrain"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        else:
+            out["terrain"] = None
         if _REPORT_FD is None and world == 1 and not args.no_box:   # --direct: no supervisor to do it; the contexts are closed by now
             wd.stage("box", 180)
             out = add_box(out)

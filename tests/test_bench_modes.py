@@ -52,6 +52,10 @@ def test_single_gpu_line_carries_roofline_and_reproducible_cpu_leg():
         assert len(q["step_ms"]) == int(w) and all(x > 0 for x in q["step_ms"]) and q["slowest_ms"] == max(q["step_ms"])
         assert abs(ps[w] - rr["world_step_ms"] / q["slowest_ms"]) < 0.01 and 0.5 < ps[w] <= int(w) * 1.5
         assert 1.0 <= q["triangles_max_over_mean"]["balanced"] <= q["triangles_max_over_mean"]["modulo"] + 1e-9
+    # SURVEY 8f rank 1 in the driver's line: the world build and interactive edits on a grid resident in HBM
+    tr = j["terrain"]
+    assert "error" not in tr, tr
+    assert tr["world_build"]["update_ms"] > 0 and tr["world_build"]["triangles"] > 0 and tr["edits"]["edit_latency_us_median"] > 0 and tr["edits"]["triangles_median"] > 0
     # BASELINE configs[4] in its short form behind the grid (256^3 here, 2048^3 in the default run)
     s2 = j["stream2048"]
     assert "error" not in s2, s2
@@ -103,27 +107,27 @@ def test_stream_config_line():
 def test_exchange_path_through_a_world_of_one_communicator():
     """The N > 1 host path of bench.py on one GPU: the library's RCCL all-gather (world of one), the pinned copy + the one
     wait through the ABI, offsets from the gathered pairs -- and the triangle total they must add up to (asserted in bench.py)."""
-    j = run([sys.executable, "bench.py", "--grid", "256", "--steps", "9", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record", "--no-box"],
+    j = run([sys.executable, "bench.py", "--grid", "256", "--steps", "9", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record", "--no-terrain-record", "--no-box"],
             {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j["n_gpus"] == 1 and abs(j["triangles_total"] - 2655156) < 2000
     assert j["allgather_ms"] is not None and j["allgather_ms"]["avg"] >= 0
     assert j["stream_count"] == 4 and "one collective stream" in j["config"]["collective"]     # the default (round 6): a stream per context, every collective of the rank on ONE ordinary stream behind its emit launch's event
-    j0 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record", "--no-box", "--streams", "1"],
+    j0 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record", "--no-terrain-record", "--no-box", "--streams", "1"],
              {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j0["stream_count"] == 1 and "one collective stream" in j0["config"]["collective"] and j0["triangles_total"] == j["triangles_total"]
     # the collective behind the emit kernel on the step's own stream (the library chains the communicator's collectives across the four streams)
-    j3 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record", "--no-box", "--gather-stream", "main"],
+    j3 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record", "--no-terrain-record", "--no-box", "--gather-stream", "main"],
              {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j3["stream_count"] == 4 and "extract's stream" in j3["config"]["collective"] and j3["triangles_total"] == j["triangles_total"]
     # the fallback's configuration, as the supervisor would start it
-    jf = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record", "--no-box", "--pipeline", "2", "--streams", "1",
+    jf = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record", "--no-terrain-record", "--no-box", "--pipeline", "2", "--streams", "1",
               "--gather-stream", "main", "--assign", "modulo"], {"VTMC_BENCH_FORCE_COMM": "1"})
     assert jf["pipeline_depth"] == 2 and jf["stream_count"] == 1 and jf["triangles_total"] == j["triangles_total"]
-    j1 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record", "--no-box", "--pipeline", "1"],
+    j1 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record", "--no-terrain-record", "--no-box", "--pipeline", "1"],
              {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j1["pipeline_depth"] == 1 and j1["stream_count"] == 1 and j1["triangles_total"] == j["triangles_total"]
     # opt-in: the collective beside the emit kernel, two contexts / communicators taking turns
-    j2 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record", "--no-box", "--pipeline", "2",
+    j2 = run([sys.executable, "bench.py", "--grid", "256", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record", "--no-terrain-record", "--no-box", "--pipeline", "2",
               "--gather-beside"], {"VTMC_BENCH_FORCE_COMM": "1"})
     assert j2["pipeline_depth"] == 2 and j2["triangles_total"] == j["triangles_total"]
 
@@ -140,7 +144,7 @@ def test_gpus_n_without_a_launcher_starts_its_own_ranks():
 
 def test_direct_mode_measures_in_one_process():
     """--direct (profilers put the program itself behind `--`): no supervisor, the worker prints the line itself; the watchdog still applies."""
-    j = run([sys.executable, "bench.py", "--direct", "--grid", "256", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record"])
+    j = run([sys.executable, "bench.py", "--direct", "--grid", "256", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal", "--no-stream-record", "--no-terrain-record"])
     assert j["n_gpus"] == 1 and j["value"] > 0 and "worker" not in j and "error" not in j["box"]
 
 
@@ -150,7 +154,7 @@ def test_a_worker_that_hangs_on_the_gpu_is_replaced_by_the_conservative_one():
     the conservative configuration, labelled."""
     e = dict(os.environ, VTMC_BENCH_TEST_HANG="warmup:4")
     p = subprocess.run([sys.executable, "bench.py", "--grid", "256", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-indexed", "--no-rehearsal",
-                        "--no-stream-record", "--no-box"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+                        "--no-stream-record", "--no-terrain-record", "--no-box"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1

@@ -24,7 +24,7 @@ T="timeout -k 10 420"
 $T python3 $R/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err; echo "bench rc=$?"
 $T python3 $R/bench.py --config stream2048 > $OUT/bench_stream2048.json 2> $OUT/bench_stream.err; echo "stream rc=$?"
 VTMC_BENCH_ONE_DEVICE=1 VTMC_BENCH_BACKEND=gloo $T python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29719 $R/bench.py --gpus 2 --steps 20 --warmup 3 > $OUT/bench_2rank_one_device_gloo.json 2> $OUT/bench_2rank.err; echo "2rank rc=$?"
-VTMC_BENCH_FORCE_COMM=1 $T python3 $R/bench.py --no-cpu-baseline --no-indexed --no-rehearsal --no-stream-record > $OUT/bench_world_of_one_comm.json 2> $OUT/bench_comm.err; echo "comm rc=$?"
+VTMC_BENCH_FORCE_COMM=1 $T python3 $R/bench.py --no-cpu-baseline --no-indexed --no-rehearsal --no-stream-record --no-terrain-record > $OUT/bench_world_of_one_comm.json 2> $OUT/bench_comm.err; echo "comm rc=$?"
 $T python3 $R/tools/rank_rehearsal_all.py --json $OUT/rank_rehearsal_all.json 2> $OUT/rank_rehearsal_all.err | grep -v "$F" > $OUT/rank_rehearsal_all.txt; echo "rehearsal rc=$?"
 $T python3 $R/tools/rank_rehearsal_all.py --gather-stream main 2> /dev/null | grep -v "$F" > $OUT/rank_rehearsal_all_gather_stream_main.txt
 $T python3 $R/tools/placement_probe.py --contexts 6 --rounds 7 2>&1 | grep -v "$F" > $OUT/placement_probe_refresh.txt

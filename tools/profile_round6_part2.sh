@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 RD="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
 WR="TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
-B="--direct --no-cpu-baseline --no-indexed --no-rehearsal --no-stream-record --no-box"
+B="--direct --no-cpu-baseline --no-indexed --no-rehearsal --no-stream-record --no-terrain-record --no-box"
 T="timeout -k 10 150"
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --warmup 3 $B > $OUT/stats/bench.json 2> $OUT/stats/err.log
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_s1 -- python3 $R/bench.py --steps 20 --warmup 3 $B --streams 1 > $OUT/stats_s1/bench.json 2> $OUT/stats_s1/err.log
