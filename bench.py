@@ -18,7 +18,7 @@ k's T and offsets, so the device goes from step to step without waiting for the 
 that extracts frame after frame would drive the library; every step still delivers its T, gather and
 offsets.  `value` is that throughput; the latency of an isolated step is reported next to it
 (`step_latency_ms`, = --pipeline 1).  Each context's output buffer is chosen among eight allocations in its first
-warm-up step (--place-outputs 8: the library's placement trials; the identical emit kernel runs 0.86 ... 1.00 ms
+warm-up step (--place-outputs 8, at most 16: the library's placement trials; the identical emit kernel runs 0.86 ... 1.00 ms
 by which allocation it writes, profiles/r06/placement_probe.txt; every candidate's time is in the line).
 
 --config stream2048 (BASELINE.json configs[4]): a 2048^3-cell fbm8 world (36 GB of samples) streamed
@@ -926,7 +926,7 @@ def run_grid(args, torch, dist, wd):
     if os.environ.get("VTMC_BENCH_TUNING"):   # A/B of kernel variants under the bench's sustained load, e.g. VTMC_BENCH_TUNING="emit_once=0"
         tuning = {k: int(v) for k, v in (item.split("=") for item in os.environ["VTMC_BENCH_TUNING"].split(","))}
     if args.place_outputs > 1 and not (tuning and "place_outputs" in tuning):
-        tuning = dict(tuning or {}, place_outputs=min(args.place_outputs, 8))
+        tuning = dict(tuning or {}, place_outputs=min(args.place_outputs, 16))
     pipe = GridPipeline(torch, vt, local, depth, args.streams == 2, args.gather_stream, args.gather_beside, tuning, args.no_dense)
     dbg = (lambda m: print("bench.py[%d]: %s" % (rank, m), file=sys.stderr, flush=True)) if os.environ.get("VTMC_BENCH_DEBUG") else (lambda m: None)
     d_field = None
@@ -983,7 +983,7 @@ def run_grid(args, torch, dist, wd):
         placement = None
         if args.place_outputs > 1:
             trials = [e.last_placement() for e in pipe.exs]
-            placement = {"candidates": min(args.place_outputs, 8),
+            placement = {"candidates": min(args.place_outputs, 16),
                          "emit_ms_by_context": [t[0] for t in trials], "kept": [t[1] for t in trials],
                          "note": "tuning key place_outputs: at each context's first warm-up step the emit stage was run into this many allocations of the output buffer "
                                  "and the fastest kept (the emit kernel's time is a property of the pair input allocation / output allocation; candidate 0 is what hipMalloc gave first)"}

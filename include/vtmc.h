@@ -193,7 +193,7 @@ int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4]);
  * "classify_wgs_per_cu" (0 or 2-7, default 3: residency cap of the streaming classify kernel; 0: none), "density_wgs_per_cu" (0, 2 or 3:
  * residency cap of the synthetic sampler), "stage_events" (default 1: HIP events between the three kernels for vtmc_last_stage_ms; 0: only around
  * the step), "gather_beside" (default 0: the all-gather of a queued extract runs behind the emit kernel on the caller's stream; 1: beside
- * it on the context's second stream), "place_outputs" (0-8, default 0: see vtmc_last_placement below).  The diagnostic keys "emit_ablate" / "classify_ablate" / "density_ablate" (parts of a kernel
+ * it on the context's second stream), "place_outputs" (0-16, default 0: see vtmc_last_placement below).  The diagnostic keys "emit_ablate" / "classify_ablate" / "density_ablate" (parts of a kernel
  * switched off, output INVALID) exist only in -DVTMC_DIAGNOSTICS builds of the library (tools/build_diagnostics.py).
  * "fill_keeps_signs" (default 0) is a contract, not a variant: with 1, vtmc_density_fill_device[_async] also leaves
  * one sign bit per sample in context memory, and an extract by the SAME context of exactly that buffer (pointer,
@@ -203,14 +203,14 @@ int32_t vtmc_last_stage_ms(vtmc_ctx *ctx, float ms[4]);
  * same address to a new buffer of the same shape calls that when it frees the old one.  streaming.ChunkStream sets it. */
 int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value);
 
-/* OUTPUT PLACEMENT (tuning key "place_outputs" = K, 2-8; default 0 = off).  The emit kernel's time is a property of the pair (allocation of the
+/* OUTPUT PLACEMENT (tuning key "place_outputs" = K, 2-16; default 0 = off).  The emit kernel's time is a property of the pair (allocation of the
  * input field, allocation of the output buffers): the identical kernel on the identical input runs 0.86 ... 1.00 ms by which allocation it
  * writes (profiles/r06/placement_probe.txt).  With K > 1, whenever the library has just (re)allocated its output buffers -- a context's first
  * extract, a growth -- it runs the emit stage of the extract at hand into K - 1 further allocations of the same size, times each and keeps the
  * fastest (an autotuner's move; the result is complete and identical in every candidate).  Cost: 2 (K - 1) emit launches and K allocations of the
  * output held at once while the trial runs (they must differ: one freed and made again gets its old pages back), once per (re)allocation.  vtmc_last_placement reports the last trial: the emit stage's milliseconds per candidate (ms[0] = the
  * allocation that was there), how many were tried (0: no trial yet) and which one was kept. */
-int32_t vtmc_last_placement(const vtmc_ctx *ctx, float ms[8], int32_t *n_candidates, int32_t *kept);
+int32_t vtmc_last_placement(const vtmc_ctx *ctx, float ms[16], int32_t *n_candidates, int32_t *kept);
 
 /* Synthetic density sampler (the reference has no noise field of its own):
  * density = sum_{o<octaves} gain^o * perlin(p*frequency*lacunarity^o) - (p.y - ramp_center)*ramp_scale,

@@ -46,6 +46,7 @@ SETS = [
     (dict(place_outputs=2), True, True),
     (dict(place_outputs=4, emit_once=0), True, False),
     (dict(place_outputs=8, stage_events=0), True, True),
+    (dict(place_outputs=16), True, False),
 ]
 
 
@@ -143,7 +144,7 @@ def test_refused_keys_and_values(ex):
     for key, value in (("one_pass", 1), ("one_pass_depth", 2), ("one_pass_unit", 1), ("one_pass_prefetch", 1), ("emit_async", 0),
                        ("emit_group_log2", 2), ("emit_ablate", 1), ("classify_ablate", 1), ("density_ablate", 1), ("no_such_key", 0),
                        ("emit_idx_waves", 3), ("emit_idx_waves", 4), ("classify_wide", 1), ("emit_sub_log2", 5), ("emit_sub_log2", -1), ("emit_wgs_per_cu", 9),
-                       ("classify_wgs_per_cu", 8), ("classify_wgs_per_cu", 1), ("density_wgs_per_cu", 1), ("density_wgs_per_cu", 4), ("emit_fast_math", 2), ("emit_once", -1), ("place_outputs", 9), ("place_outputs", -1),
+                       ("classify_wgs_per_cu", 8), ("classify_wgs_per_cu", 1), ("density_wgs_per_cu", 1), ("density_wgs_per_cu", 4), ("emit_fast_math", 2), ("emit_once", -1), ("place_outputs", 17), ("place_outputs", -1),
                        ("classify_column", 4), ("classify_column_wgs", 2)):
         with pytest.raises(vt.VtmcError) as e:
             ex.set_tuning(**{key: value})

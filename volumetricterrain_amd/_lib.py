@@ -122,7 +122,7 @@ def load(path=None):
     if not explicit or hasattr(L, "vtmc_release_streams"):
         L.vtmc_release_streams.argtypes = []
     if not explicit or hasattr(L, "vtmc_last_placement"):
-        L.vtmc_last_placement.argtypes = [vp, P(ctypes.c_float * 8), P(i32), P(i32)]
+        L.vtmc_last_placement.argtypes = [vp, P(ctypes.c_float * 16), P(i32), P(i32)]
     L.vtmc_device_results.argtypes = [vp, P(vp), P(vp), P(vp)]
     L.vtmc_reserve_triangles.argtypes = [vp, i64]
     L.vtmc_copy_volume_counts_device.argtypes = [vp, vp, i32, vp]

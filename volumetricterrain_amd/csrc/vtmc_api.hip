@@ -313,7 +313,7 @@ int extract_queue(vtmc_ctx *ctx, const BlockSpace &sp, int n_volumes, uint32_t f
 int place_outputs(vtmc_ctx *ctx)
 {
     const VtmcPending &pe = ctx->pending;
-    const int K = std::min(ctx->tune.place_outputs, 8);
+    const int K = std::min(ctx->tune.place_outputs, 16);
     // the buffers the emit stage of this extract writes: the triangle records, or (indexed output) the index and vertex buffers
     DevBuf &A = pe.indexed ? ctx->indices : ctx->tris;
     DevBuf none;
@@ -976,7 +976,7 @@ int32_t vtmc_context_stream(vtmc_ctx *ctx, int32_t own_queue, void **stream)
     return VTMC_OK;
 }
 
-int32_t vtmc_last_placement(const vtmc_ctx *ctx, float ms[8], int32_t *n_candidates, int32_t *kept)
+int32_t vtmc_last_placement(const vtmc_ctx *ctx, float ms[16], int32_t *n_candidates, int32_t *kept)
 {
     if (!ctx) return VTMC_ERR_INVALID_ARG;
     if (ms) memcpy(ms, ctx->place_ms, sizeof ctx->place_ms);
@@ -1020,7 +1020,7 @@ int32_t vtmc_set_tuning(vtmc_ctx *ctx, const char *key, int32_t value)
     if (k == "classify_wgs_per_cu") return ranged(ctx->tune.classify_wgs_per_cu, 0, 7);
     if (k == "density_wgs_per_cu") return ranged(ctx->tune.density_wgs_per_cu, 0, 3);
     if (k == "gather_beside") return ranged(ctx->tune.gather_beside, 0, 1);
-    if (k == "place_outputs") return ranged(ctx->tune.place_outputs, 0, 8);
+    if (k == "place_outputs") return ranged(ctx->tune.place_outputs, 0, 16);
     if (k == "stage_events") return ranged(ctx->tune.stage_events, 0, 1);
     if (k == "invalidate_signs") {   // the caller wrote to (or re-used the address of) a buffer the last fill left sign bits for
         ctx->sign_of.valid = false;

@@ -58,7 +58,7 @@ struct vtmc_ctx {
     bool origins_upload_pending = false;
     float stage_ms[4] = {0, 0, 0, 0};
     bool place_pending = false;     // the output buffers were (re)allocated since the last placement trial (tuning key place_outputs)
-    float place_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // emit stage per candidate of the last trial ([0]: the buffer that was there), place_n of them
+    float place_ms[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // emit stage per candidate of the last trial ([0]: the buffer that was there), place_n of them
     int place_n = 0, place_kept = 0;
     hipEvent_t ev_fill[2] = {nullptr, nullptr};  // around the last density kernel (vtmc_last_fill_ms)
     bool fill_timed = false;

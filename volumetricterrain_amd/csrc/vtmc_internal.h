@@ -96,7 +96,7 @@ struct Tuning {
     int stage_events = 1;     // 1: events between the three kernels (vtmc_last_stage_ms per stage); 0: only around the whole step
     int gather_beside = 0;    // 1: the all-gather of a queued extract runs on a second stream beside the emit kernel (opt-in: never run with a world > 1); 0: behind it, on the caller's stream
     int emit_once = 1;        // 1 (soup, fast math): every welded vertex of a block is evaluated once into LDS, records expanded from there; 0: per triangle corner
-    int place_outputs = 0;    // round 6: > 1 = when the output buffers have just been (re)allocated, that many candidate allocations are timed with the emit stage of the
+    int place_outputs = 0;    // round 6: > 1 (up to 16) = when the output buffers have just been (re)allocated, that many candidate allocations are timed with the emit stage of the
                               // extract at hand and the fastest kept (profiles/r06/placement_probe.txt: the emit kernel's time is a property of the pair
                               // input field / output allocation, 0.86-1.00 ms for one kernel); 0 / 1: take what hipMalloc gives
     int emit_spare_wgs = 0;   // workgroups the emit launch leaves free (one per XCD: room for the collective's kernel beside it)

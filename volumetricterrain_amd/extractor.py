@@ -242,7 +242,7 @@ class Extractor:
 
     def last_placement(self):
         """The last output-placement trial (tuning key place_outputs): ([emit ms per candidate], index kept); ([], 0) when none has run."""
-        ms, n, kept = (ctypes.c_float * 8)(), ctypes.c_int32(), ctypes.c_int32()
+        ms, n, kept = (ctypes.c_float * 16)(), ctypes.c_int32(), ctypes.c_int32()
         self._check(self._L.vtmc_last_placement(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(kept)))
         return [round(float(ms[i]), 4) for i in range(n.value)], kept.value
 
