@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Same-box, same-PROCESS A/B of library builds: boxes of the pool drift by several percent from one process to the next (clock / power
-state), more than most kernel changes are worth, so alternating processes (tools/ab_two_builds.sh) cannot resolve them.  Every build is
+state), more than most kernel changes are worth, so alternating processes cannot resolve them.  Round 6: the build listed FIRST draws the first context's
+output buffers, whose allocation decides the emit kernel's level (profiles/r06/placement_probe.txt) -- run both orders, or give every context
+placement trials (append place_outputs=8 to a variant).  Every build is
 loaded beside the others (its own ctypes handle, its own context), the rounds alternate build by build and variant by variant.
 
-    python tools/ab_two_libs.py new=volumetricterrain_amd/libvtmc.so prev=tools/_ab/libvtmc_prev.so -- base indexed=1 emit_once=0 [--rounds 9]
+    python tools/ab_two_libs.py new=volumetricterrain_amd/libvtmc.so r05=tools/_ab/libvtmc_r05.so -- base indexed=1 emit_once=0 [--rounds 9]
 """
 import argparse
 import os
